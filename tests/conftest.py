@@ -1,0 +1,46 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """Golden vectors produced by the reference's own Python (tests/golden/make_golden.py)."""
+
+    def __init__(self):
+        d = os.path.join(ROOT, "tests", "golden")
+        with open(os.path.join(d, "pq_golden.json")) as f:
+            self.manifest = json.load(f)
+        self.arrays = np.load(os.path.join(d, "pq_golden.npz"), allow_pickle=False)
+
+    def cases(self, kind=None):
+        return [c for c in self.manifest["cases"] if kind is None or c["kind"] == kind]
+
+    def get(self, case, name):
+        key = f"{case['id']}_{name}"
+        return self.arrays[key] if key in self.arrays.files else None
+
+
+_GOLDEN = None
+
+
+def golden():
+    global _GOLDEN
+    if _GOLDEN is None:
+        _GOLDEN = Golden()
+    return _GOLDEN
+
+
+@pytest.fixture(scope="session")
+def gold():
+    return golden()
