@@ -1,0 +1,114 @@
+/*
+ * pq_amd.h -- C ABI of libpq_amd.so: the MI355X (gfx950) product-quantised linear layer.
+ *
+ * This is the boundary a host runtime binds (ctypes / cgo / JNI / a torch custom op).  It replaces,
+ * for the PQ / AQLM tensor format, the native ops the reference registers in its torch extension:
+ *
+ *   pq_dequant  <->  aqlm_dequant(Tensor codes, Tensor codebooks, int[] codebook_partition_sizes)
+ *                    csrc/torch_bindings.cpp:168-173, csrc/ops.h:128-131,
+ *                    csrc/quantization/aqlm/gemm_kernels.cu:544-597, vllm/_custom_ops.py:360-371;
+ *                    with scales != NULL it is dequantize_weight(codes, codebooks, scales) per
+ *                    partition, vllm/model_executor/layers/quantization/aqlm.py:37-74, :105-126
+ *   pq_gemm     <->  aqlm_gemm(Tensor input, Tensor codes, Tensor codebooks, Tensor scales,
+ *                              int[] codebook_partition_sizes, Tensor? bias)
+ *                    csrc/torch_bindings.cpp:160-166, csrc/ops.h:122-126,
+ *                    csrc/quantization/aqlm/gemm_kernels.cu:519-542, vllm/_custom_ops.py:347-358;
+ *                    numerically it is generic_dequantize_gemm, aqlm.py:94-127
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to memory the caller owns; the library never allocates,
+ *     frees or keeps a pointer, and starts no threads.  `stream` is the caller's hipStream_t
+ *     (NULL = the default stream); calls only enqueue work on it and never synchronise, so they
+ *     can be captured into a HIP graph.
+ *   - return value: PQ_OK (0) or a pq_status code; pq_last_error() gives a thread-local message.
+ *     No C++ exception crosses the boundary.
+ *   - fp16 / bf16 ("act dtype") selected by `dtype`; codebooks, scales, bias, x and y share it.
+ *
+ * Tensor layouts (row-major, contiguous unless a stride argument says otherwise), exactly the
+ * parameters AQLMLinearMethod.create_weights registers (aqlm.py:253-316):
+ *   codes      [N][G][M]      int8 (code_bytes 1) or int16 (code_bytes 2), signed storage;
+ *                             index = value mod K (aqlm.py:32-34), K = 2^nbits
+ *   codebooks  [P*M][K][1][d] act dtype; rows p*M .. p*M+M-1 belong to output partition p
+ *   scales     [N][1][1][1]   act dtype, one per output row
+ *   part_sizes [P]            HOST array: rows per output partition (q/k/v, gate/up), sum = N
+ *   x          [T][Kin]       act dtype, Kin = G*d;  y [T][N] act dtype
+ */
+#ifndef PQ_AMD_H
+#define PQ_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PQ_ABI_VERSION 1
+#define PQ_MAX_PARTS 8 /* the reference's kernels take at most 4 (gemm_kernels.cu:499-514) */
+
+typedef enum pq_dtype { PQ_DTYPE_FP16 = 0, PQ_DTYPE_BF16 = 1 } pq_dtype;
+
+typedef enum pq_status {
+    PQ_OK = 0,
+    PQ_ERR_INVALID_ARGUMENT = 1, /* shape / pointer / partition list rejected */
+    PQ_ERR_UNSUPPORTED = 2,      /* a format this build has no kernel for */
+    PQ_ERR_WORKSPACE = 3,        /* workspace too small */
+    PQ_ERR_LAUNCH = 4            /* the HIP runtime reported an error at launch */
+} pq_status;
+
+/* capability bits of pq_caps() */
+#define PQ_CAP_DEQUANT (1ull << 0)
+#define PQ_CAP_GEMM (1ull << 1)
+#define PQ_CAP_MFMA_SMALL_T (1ull << 2) /* fused gather+MFMA streaming kernel (decode) */
+#define PQ_CAP_MFMA_TILED (1ull << 3)   /* fused gather+MFMA tiled kernel (prefill)   */
+#define PQ_CAP_BF16 (1ull << 4)
+#define PQ_CAP_FP16 (1ull << 5)
+
+/* Version of this ABI (PQ_ABI_VERSION) and capability bits.  No reference counterpart. */
+int pq_version(void);
+uint64_t pq_caps(void);
+
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char *pq_last_error(void);
+
+/*
+ * Reconstruct the dense weight  W[n][g*d + j] = sum_m codebooks[p(n)*M + m][idx(n,g,m)][j]
+ * (x scales[n] when scales != NULL), out [N][G*d] in the act dtype.
+ * M == 1 and scales == NULL is a pure gather and is bit-exact.  M > 1 sums in fp32 and rounds
+ * once (nearest even); the scale multiply is one more rounding, as Tensor.mul does.
+ * Replaces aqlm_dequant (gemm_kernels.cu:544-597) / dequantize_weight (aqlm.py:37-74).
+ */
+int pq_dequant(const void *codes, const void *codebooks, const void *scales /* nullable */,
+               const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K,
+               int32_t d, int32_t code_bytes, int32_t dtype, void *out, void *stream);
+
+/*
+ * Bytes of scratch pq_gemm needs for this problem (0 when none).  The caller allocates it once
+ * (any 256-byte aligned device memory) and may reuse it for every call of the same or a smaller
+ * problem on the same stream.  No reference counterpart (the reference allocates inside the op).
+ */
+size_t pq_gemm_workspace_bytes(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d,
+                               int32_t code_bytes, int32_t dtype);
+
+/*
+ * y[t][n] = act( scales[n] * sum_k x[t][k] * Wunscaled[n][k] + bias[n] ), accumulated in fp32 with
+ * one rounding at the end.  x rows are x_row_stride elements apart, y rows y_row_stride.
+ * bias may be NULL.  Replaces aqlm_gemm (gemm_kernels.cu:519-542) and, for every format the
+ * reference routes to PyTorch, generic_dequantize_gemm (aqlm.py:94-127).
+ */
+int pq_gemm(const void *x, int32_t T, int64_t x_row_stride, const void *codes, const void *codebooks,
+            const void *scales, const void *bias /* nullable */, const int32_t *part_sizes, int32_t num_parts,
+            int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype, void *y,
+            int64_t y_row_stride, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Which kernel pq_gemm would run for this problem: writes a short name ("mfma_stream", "mfma_tiled",
+ * "generic") into buf.  For tests, benchmarks and profiles.  No reference counterpart.
+ */
+int pq_gemm_kernel_name(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes,
+                        int32_t dtype, const int32_t *part_sizes, int32_t num_parts, char *buf, size_t buf_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQ_AMD_H */

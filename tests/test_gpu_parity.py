@@ -1,0 +1,225 @@
+"""Parity of the HIP path (through the C ABI, libpq_amd.so) with the CPU oracle and with the golden
+vectors produced by the reference's own Python.  Runs on a real MI355X: `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import pq_oracle as orc
+from pq_testlib import (Problem, assert_close_to_exact, assert_close_to_reference_order, bits_of, tensor_of)
+
+pytestmark = pytest.mark.gpu
+G = golden()
+DEV = "cuda:0"
+
+
+def _id(c):
+    return f"{c['id']}-K{c['K']}d{c['d']}M{c['M']}-{c['dtype']}"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from vllm_pq_amd import ops as o
+    return o
+
+
+def _golden_tensors(case):
+    dt = case["dtype"]
+    codes = torch.from_numpy(G.get(case, "codes")).to(DEV)
+    cb = tensor_of(G.get(case, "codebooks"), dt, DEV)
+    sc = G.get(case, "scales")
+    sc = None if sc is None else tensor_of(sc, dt, DEV)
+    return codes, cb, sc
+
+
+# ---- gather / dequant: bit-exact --------------------------------------------------------------
+@pytest.mark.parametrize("case", G.cases("gather"), ids=_id)
+def test_gather_golden_bit_exact(ops, case):
+    codes, cb, _ = _golden_tensors(case)
+    out = ops.pq_dequant(codes, cb, case["parts"])
+    assert np.array_equal(bits_of(out), G.get(case, "out"))
+
+
+@pytest.mark.parametrize("case", G.cases("dequant"), ids=_id)
+def test_scaled_dequant_golden(ops, case):
+    codes, cb, sc = _golden_tensors(case)
+    out = bits_of(ops.pq_dequant(codes, cb, case["parts"], sc))
+    # the oracle in nearest-even mode is the bit-exact target (M >= 2 bf16: torch's CPU kernel rounds
+    # exact ties of the codebook sum away from zero, the HIP kernel to even; see oracle/pq_oracle.c)
+    want = orc.dequant(G.get(case, "codes"), G.get(case, "codebooks").reshape(-1, case["K"], case["d"]),
+                       G.get(case, "scales").reshape(-1), case["parts"], case["dtype"])
+    assert np.array_equal(out, want)
+    if case["M"] == 1 or case["dtype"] == "fp16":
+        assert np.array_equal(out, G.get(case, "out"))
+    else:
+        gold = G.get(case, "out")
+        diff = np.abs(orc.to_f32(out, "bf16") - orc.to_f32(gold, "bf16"))
+        assert (out != gold).mean() < 0.15 and (diff <= 2 * 2.0 ** -7 * np.abs(orc.to_f32(gold, "bf16")) * 1.01).all()
+
+
+@pytest.mark.parametrize("K,d,M,parts,Kin,dtype", [
+    (256, 8, 1, [1024, 256, 256], 4096, "bf16"),     # Llama-3-8B qkv at TP=4
+    (256, 8, 1, [512], 14336, "bf16"),               # down_proj rows
+    (256, 4, 1, [768, 768, 768], 768, "fp16"),       # OPT-125m qkv
+    (16, 2, 1, [256], 512, "bf16"),
+    (4096, 8, 1, [256], 1024, "bf16"),
+    (4096, 4, 2, [64, 64], 256, "fp16"),             # codebooks too large for LDS -> L2 gather
+    (256, 8, 2, [200, 56], 1000, "bf16"),            # ragged: Kin % 8 == 0, odd partition sizes
+    (256, 3, 1, [33, 31], 99, "bf16"),               # d not a divisor of 8 -> element kernel
+    (65536, 8, 1, [64], 512, "fp16"),                # AQLM 1x16
+])
+def test_dequant_seeded(ops, K, d, M, parts, Kin, dtype):
+    p = Problem(7, K, d, M, parts, Kin, 1, dtype, scales="normal").to(DEV)
+    for scaled in (False, True):
+        out = ops.pq_dequant(p.codes_dev, p.codebooks_dev, parts, p.scales_dev if scaled else None)
+        assert np.array_equal(bits_of(out), p.oracle_dequant(scaled)), f"scaled={scaled}"
+
+
+# ---- fused GEMM ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", ["auto", "generic"])
+@pytest.mark.parametrize("case", G.cases("gemm"), ids=_id)
+def test_gemm_golden(ops, case, kernel, monkeypatch):
+    monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "" if kernel == "auto" else kernel)
+    dt = case["dtype"]
+    codes, cb, sc = _golden_tensors(case)
+    x = tensor_of(G.get(case, "x"), dt, DEV)
+    b = G.get(case, "bias")
+    b = None if b is None else tensor_of(b, dt, DEV)
+    y = bits_of(ops.pq_gemm(x, codes, cb, sc, case["parts"], b))
+    assert y.shape == (case["T"], case["N"])
+    _, y32 = orc.gemm(G.get(case, "x"), G.get(case, "codes"), G.get(case, "codebooks").reshape(-1, case["K"], case["d"]),
+                      G.get(case, "scales").reshape(-1), case["parts"], G.get(case, "bias"), dt, order=2,
+                      acc_double=True, want_f32=True)
+    assert_close_to_exact(y, y32, dt, "vs exact")
+    assert_close_to_reference_order(y, G.get(case, "out"), dt, "vs reference output")
+
+
+SEEDED = [
+    # (K, d, M, parts, Kin, T, dtype, bias)
+    (256, 8, 1, [1024, 256, 256], 4096, 1, "bf16", False),    # Llama-3-8B qkv, TP=4
+    (256, 8, 1, [1024, 256, 256], 4096, 16, "bf16", False),
+    (256, 8, 1, [1024, 256, 256], 4096, 37, "bf16", False),
+    (256, 8, 1, [512], 3584, 5, "bf16", False),               # down_proj K slice at TP=4 (7 chunks)
+    (256, 8, 1, [896, 896], 4096, 8, "fp16", False),          # gate_up slice
+    (256, 4, 1, [768, 768, 768], 768, 9, "fp16", True),       # OPT-125m qkv, bias live
+    (256, 4, 1, [768], 3072, 3, "bf16", True),                # OPT-125m fc2
+    (16, 8, 1, [512], 512, 4, "bf16", False),
+    (16, 4, 1, [512], 512, 16, "fp16", True),
+    (16, 2, 1, [256], 512, 2, "bf16", False),
+    (256, 2, 1, [256], 512, 16, "bf16", False),
+    (4096, 8, 1, [256], 1024, 6, "bf16", True),
+    (4096, 4, 1, [256], 512, 1, "fp16", False),
+    (4096, 2, 1, [128], 256, 16, "bf16", False),
+    (256, 8, 2, [512, 512], 1024, 6, "fp16", True),           # AQLM 2x8
+    (65536, 8, 1, [64], 512, 2, "fp16", False),               # AQLM 1x16 -> generic kernel
+    (256, 8, 1, [100, 60], 136, 3, "bf16", True),             # ragged -> generic kernel
+    (256, 8, 1, [40, 24], 128, 70, "bf16", False),            # partial row tiles, T > 64
+]
+
+
+@pytest.mark.parametrize("K,d,M,parts,Kin,T,dtype,bias", SEEDED)
+def test_gemm_seeded(ops, K, d, M, parts, Kin, T, dtype, bias):
+    p = Problem(1234, K, d, M, parts, Kin, T, dtype, bias=bias).to(DEV)
+    y = ops.pq_gemm(p.x_dev, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    assert y.dtype == p.x_dev.dtype and y.shape == (T, p.N)
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(y), y32, dtype)
+    ref0 = p.oracle_gemm(order=0, want_f32=False)
+    assert_close_to_reference_order(bits_of(y), ref0, dtype)
+
+
+def test_gemm_input_shapes_and_strides(ops):
+    p = Problem(5, 256, 8, 1, [256], 512, 12, "bf16", bias=True).to(DEV)
+    want = ops.pq_gemm(p.x_dev, p.codes_dev, p.codebooks_dev, p.scales_dev, [256], p.bias_dev)
+    # [batch, seq, K] input keeps its leading dims (aqlm.py:103)
+    y3 = ops.pq_gemm(p.x_dev.view(3, 4, 512), p.codes_dev, p.codebooks_dev, p.scales_dev, [256], p.bias_dev)
+    assert y3.shape == (3, 4, 256) and torch.equal(y3.view(12, 256), want)
+    # row-strided view (a column slice of a wider activation)
+    wide = torch.zeros(12, 1024, dtype=torch.bfloat16, device=DEV)
+    wide[:, :512] = p.x_dev
+    ys = ops.pq_gemm(wide[:, :512], p.codes_dev, p.codebooks_dev, p.scales_dev, [256], p.bias_dev)
+    assert torch.equal(ys, want)
+    # the input is not modified, an empty batch gives an empty result
+    assert torch.equal(wide[:, :512], p.x_dev)
+    y0 = ops.pq_gemm(p.x_dev[:0], p.codes_dev, p.codebooks_dev, p.scales_dev, [256], None)
+    assert y0.shape == (0, 256)
+
+
+def test_gemm_one_hot_rows_reproduce_the_gather(ops):
+    """x = e_k makes y[k][n] = act(scale[n] * W[n][k]): the GEMM path decodes exactly the entries the
+    bit-exact gather does."""
+    K, d, parts, Kin = 256, 8, [256, 128], 256
+    p = Problem(11, K, d, 1, parts, Kin, Kin, "bf16").to(DEV)
+    eye = torch.eye(Kin, dtype=torch.bfloat16, device=DEV)
+    y = ops.pq_gemm(eye, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)       # [Kin, N]
+    w = ops.pq_dequant(p.codes_dev, p.codebooks_dev, parts)                             # [N, Kin]
+    want = (w.float() * p.scales_dev.view(-1, 1).float()).to(torch.bfloat16).t().contiguous()
+    assert torch.equal(y, want)
+
+
+@pytest.mark.parametrize("name,parts,Kin", [
+    ("qkv_proj", [4096, 1024, 1024], 4096), ("o_proj", [4096], 4096),
+    ("gate_up_proj", [14336, 14336], 4096), ("down_proj", [4096], 14336)])
+@pytest.mark.parametrize("T", [1, 16])
+def test_llama3_8b_full_size_properties(ops, name, parts, Kin, T):
+    """BASELINE sizes (Llama-3-8B, K=256, d=8, bf16, TP=1): too large for the CPU oracle in a test, so
+    check size-independent properties on the device: (1) the gather equals torch's own index_select
+    bit for bit; (2) the fused GEMM equals an fp32 matmul over that weight to the stated tolerance."""
+    torch.manual_seed(0)
+    N, G = sum(parts), Kin // 8
+    codes = torch.randint(-128, 128, (N, G, 1), dtype=torch.int8, device=DEV)
+    cb = torch.randn(len(parts), 256, 1, 8, device=DEV).to(torch.bfloat16)
+    scales = (torch.rand(N, 1, 1, 1, device=DEV) + 0.5).to(torch.bfloat16)
+    x = torch.randn(T, Kin, device=DEV).to(torch.bfloat16)
+    w = ops.pq_dequant(codes, cb, parts)
+    off = 0
+    for pi, sz in enumerate(parts):
+        idx = (codes[off:off + sz, :, 0].long() & 255).reshape(-1)
+        want = cb[pi, :, 0, :].index_select(0, idx).view(sz, Kin)
+        assert torch.equal(w[off:off + sz], want)
+        off += sz
+    y = ops.pq_gemm(x, codes, cb, scales, parts, None)
+    ref = (x.float() @ w.float().t()) * scales.view(1, -1).float()
+    rms = ref.pow(2).mean().sqrt()
+    tol = 0.51 * 2.0 ** -7 * ref.abs() + 1e-4 * rms        # fp32 reference itself carries ~1e-5 rms noise
+    assert ((y.float() - ref).abs() <= tol).all()
+
+
+# ---- through the plugin surface -------------------------------------------------------------------
+def test_apply_through_parallel_linear_layers(ops):
+    from vllm_pq_amd import PQConfig, PQLinearMethod
+    from vllm_pq_amd.host.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+    cfg = PQConfig(8, 8, 1, 1)
+    torch.manual_seed(1)
+    qkv = QKVParallelLinear(512, 64, 8, 2, bias=False, params_dtype=torch.bfloat16, quant_config=cfg)
+    gate_up = MergedColumnParallelLinear(512, [1024, 1024], bias=False, params_dtype=torch.bfloat16, quant_config=cfg)
+    down = RowParallelLinear(1024, 512, bias=True, params_dtype=torch.bfloat16, quant_config=cfg)
+    for layer in (qkv, gate_up, down):
+        assert isinstance(layer.quant_method, PQLinearMethod)
+        layer.codes.data = torch.randint(-128, 128, layer.codes.shape, dtype=torch.int8)
+        layer.codebooks.data = torch.randn(layer.codebooks.shape).to(torch.bfloat16)
+        layer.scales.data = (torch.rand(layer.scales.shape) + 0.5).to(torch.bfloat16)
+        if layer.bias is not None:
+            layer.bias.data = torch.randn(layer.bias.shape).to(torch.bfloat16)
+        layer.to(DEV)
+        layer.quant_method.process_weights_after_loading(layer)
+        x = torch.randn(5, layer.input_size, device=DEV).to(torch.bfloat16)
+        y, out_bias = layer(x)
+        assert out_bias is None
+        parts = layer.codebooks.output_partition_sizes
+        _, y32 = orc.gemm(bits_of(x), layer.codes.cpu().numpy(), bits_of(layer.codebooks).reshape(-1, 256, 8),
+                          bits_of(layer.scales).reshape(-1), parts,
+                          None if layer.bias is None else bits_of(layer.bias), "bf16", order=2, want_f32=True)
+        assert_close_to_exact(bits_of(y), y32, "bf16", type(layer).__name__)
+
+
+def test_ops_reject_cpu_tensors_and_bad_shapes(ops):
+    p = Problem(3, 256, 8, 1, [64], 128, 2, "bf16")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.pq_gemm(p.x, p.codes, p.codebooks, p.scales, [64], None)
+    p.to(DEV)
+    with pytest.raises(ValueError):
+        ops.pq_gemm(p.x_dev, p.codes_dev, p.codebooks_dev, p.scales_dev, [32, 16], None)   # sum != N, P*M mismatch
+    with pytest.raises(ValueError):
+        ops.pq_gemm(p.x_dev[:, :64], p.codes_dev, p.codebooks_dev, p.scales_dev, [64], None)

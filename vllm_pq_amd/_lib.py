@@ -1,0 +1,77 @@
+"""ctypes binding of libpq_amd.so (C ABI: include/pq_amd.h).
+
+The library is the only compute path of this package: if it cannot be loaded, or a tensor is not
+on a ROCm device, the ops raise -- there is no CPU or PyTorch fallback.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("PQ_AMD_LIB", os.path.join(_HERE, "libpq_amd.so"))
+
+PQ_ABI_VERSION = 1
+PQ_MAX_PARTS = 8
+PQ_DTYPE_FP16, PQ_DTYPE_BF16 = 0, 1
+
+# every symbol include/pq_amd.h declares
+EXPORTS = ("pq_version", "pq_caps", "pq_last_error", "pq_dequant", "pq_gemm_workspace_bytes", "pq_gemm",
+           "pq_gemm_kernel_name")
+
+_lock = threading.Lock()
+_lib = None
+
+
+class PQLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpq_amd.so once; raises PQLibraryError when it is missing or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise PQLibraryError(
+                f"{LIB_PATH} not found: build it with `make -C vllm_pq_amd/csrc` (or __graft_entry__.build()); "
+                "vllm_pq_amd has no fallback path")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise PQLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        missing = [s for s in EXPORTS if not hasattr(L, s)]
+        if missing:
+            raise PQLibraryError(f"{LIB_PATH} lacks symbols {missing}")
+        vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+        pi32 = ctypes.POINTER(ctypes.c_int32)
+        L.pq_version.argtypes = []
+        L.pq_version.restype = ctypes.c_int
+        L.pq_caps.argtypes = []
+        L.pq_caps.restype = ctypes.c_uint64
+        L.pq_last_error.argtypes = []
+        L.pq_last_error.restype = ctypes.c_char_p
+        L.pq_dequant.argtypes = [vp, vp, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+        L.pq_dequant.restype = ctypes.c_int
+        L.pq_gemm_workspace_bytes.argtypes = [i32] * 8
+        L.pq_gemm_workspace_bytes.restype = sz
+        L.pq_gemm.argtypes = [vp, i32, i64, vp, vp, vp, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64,
+                              vp, sz, vp]
+        L.pq_gemm.restype = ctypes.c_int
+        L.pq_gemm_kernel_name.argtypes = [i32] * 8 + [pi32, i32, ctypes.c_char_p, sz]
+        L.pq_gemm_kernel_name.restype = ctypes.c_int
+        if L.pq_version() != PQ_ABI_VERSION:
+            raise PQLibraryError(f"{LIB_PATH}: ABI version {L.pq_version()} != {PQ_ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return load().pq_last_error().decode("utf-8", "replace")
+
+
+def parts_array(sizes):
+    arr = (ctypes.c_int32 * len(sizes))(*[int(s) for s in sizes])
+    return arr

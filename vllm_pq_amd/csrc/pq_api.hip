@@ -1,0 +1,160 @@
+// C ABI of libpq_amd.so (declared in include/pq_amd.h): argument checking, kernel selection,
+// error reporting.  No allocation, no synchronisation, no global mutable state besides the
+// thread-local error text.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "pq_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(pq_status code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return (int)code;
+}
+
+bool is_pow2(int v) { return v >= 2 && (v & (v - 1)) == 0; }
+
+// Common format checks; mirrors the reference's own preconditions:
+//   K a power of two            (nbits = K.bit_length() - 1, aqlm.py:86)
+//   sum(part_sizes) == N        (aqlm.py:111-112)
+//   codes wide enough for K     (get_int_dtype, aqlm.py:20-29)
+int check_format(const char *fn, const int32_t *part_sizes, int num_parts, int N, int G, int M, int K, int d,
+                 int code_bytes, int dtype, pq::Parts *out) {
+    if (num_parts < 1 || num_parts > PQ_MAX_PARTS)
+        return fail(PQ_ERR_INVALID_ARGUMENT, "%s: num_parts=%d outside [1, %d]", fn, num_parts, PQ_MAX_PARTS);
+    if (!part_sizes) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: part_sizes is NULL", fn);
+    if (N < 0 || G < 0 || M < 1 || d < 1)
+        return fail(PQ_ERR_INVALID_ARGUMENT, "%s: bad shape N=%d G=%d M=%d d=%d", fn, N, G, M, d);
+    if (!is_pow2(K)) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: K=%d is not a power of two >= 2", fn, K);
+    if (code_bytes != 1 && code_bytes != 2)
+        return fail(PQ_ERR_UNSUPPORTED, "%s: code_bytes=%d (int8 and int16 codes are supported)", fn, code_bytes);
+    if ((code_bytes == 1 && K > 256) || (code_bytes == 2 && K > 65536))
+        return fail(PQ_ERR_INVALID_ARGUMENT, "%s: K=%d does not fit %d-byte codes", fn, K, code_bytes);
+    if (dtype != PQ_DTYPE_FP16 && dtype != PQ_DTYPE_BF16)
+        return fail(PQ_ERR_INVALID_ARGUMENT, "%s: dtype=%d is neither fp16 (0) nor bf16 (1)", fn, dtype);
+    if ((int64_t)G * d > INT32_MAX) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: in_features overflow", fn);
+    long long tot = 0;
+    out->num = num_parts;
+    for (int p = 0; p < PQ_MAX_PARTS; ++p) out->size[p] = 0;
+    for (int p = 0; p < num_parts; ++p) {
+        if (part_sizes[p] < 0) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: part_sizes[%d]=%d", fn, p, part_sizes[p]);
+        out->size[p] = part_sizes[p];
+        tot += part_sizes[p];
+    }
+    if (tot != N)
+        return fail(PQ_ERR_INVALID_ARGUMENT, "%s: sum(part_sizes)=%lld != N=%d", fn, tot, N);
+    return PQ_OK;
+}
+
+enum Kernel { K_GENERIC = 0, K_STREAM = 1, K_TILED = 2 };
+
+Kernel choose(const pq::GemmArgs &a) {
+    const char *force = getenv("PQ_AMD_FORCE_KERNEL");  // "generic" | "stream" | "tiled": tests and profiling
+    if (force && *force) {
+        if (!strcmp(force, "generic")) return K_GENERIC;
+        if (!strcmp(force, "stream") && pq::gemm_stream_supported(a)) return K_STREAM;
+        if (!strcmp(force, "tiled") && pq::gemm_tiled_supported(a)) return K_TILED;
+    }
+    const bool st = pq::gemm_stream_supported(a);
+    const bool ti = pq::gemm_tiled_supported(a);
+    if (ti && (a.T > 32 || !st)) return K_TILED;
+    if (st) return K_STREAM;
+    return K_GENERIC;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pq_version(void) { return PQ_ABI_VERSION; }
+
+uint64_t pq_caps(void) {
+    return PQ_CAP_DEQUANT | PQ_CAP_GEMM | PQ_CAP_MFMA_SMALL_T | PQ_CAP_MFMA_TILED | PQ_CAP_BF16 | PQ_CAP_FP16;
+}
+
+const char *pq_last_error(void) { return g_err; }
+
+int pq_dequant(const void *codes, const void *codebooks, const void *scales, const int32_t *part_sizes,
+               int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes,
+               int32_t dtype, void *out, void *stream) {
+    pq::DequantArgs a;
+    int rc = check_format("pq_dequant", part_sizes, num_parts, N, G, M, K, d, code_bytes, dtype, &a.parts);
+    if (rc) return rc;
+    if (N == 0 || G == 0) return PQ_OK;
+    if (!codes || !codebooks || !out) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_dequant: NULL tensor pointer");
+    a.codes = codes; a.codebooks = codebooks; a.scales = scales;
+    a.N = N; a.G = G; a.M = M; a.K = K; a.d = d; a.code_bytes = code_bytes; a.dtype = dtype; a.out = out;
+    hipError_t e = pq::launch_dequant(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "pq_dequant: %s", hipGetErrorString(e));
+    return PQ_OK;
+}
+
+size_t pq_gemm_workspace_bytes(int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t) {
+    return 0;  // no kernel of this build needs scratch
+}
+
+static int fill_gemm(pq::GemmArgs &a, const char *fn, const void *x, int32_t T, int64_t x_row_stride,
+                     const void *codes, const void *codebooks, const void *scales, const void *bias,
+                     const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K,
+                     int32_t d, int32_t code_bytes, int32_t dtype, void *y, int64_t y_row_stride) {
+    int rc = check_format(fn, part_sizes, num_parts, N, G, M, K, d, code_bytes, dtype, &a.parts);
+    if (rc) return rc;
+    if (T < 0) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: T=%d", fn, T);
+    if (x_row_stride < (int64_t)G * d)
+        return fail(PQ_ERR_INVALID_ARGUMENT, "%s: x_row_stride=%lld < in_features=%lld", fn, (long long)x_row_stride,
+                    (long long)G * d);
+    if (y_row_stride < N)
+        return fail(PQ_ERR_INVALID_ARGUMENT, "%s: y_row_stride=%lld < N=%d", fn, (long long)y_row_stride, N);
+    a.x = x; a.T = T; a.x_stride = x_row_stride; a.codes = codes; a.codebooks = codebooks; a.scales = scales;
+    a.bias = bias; a.N = N; a.G = G; a.M = M; a.K = K; a.d = d; a.code_bytes = code_bytes; a.dtype = dtype;
+    a.y = y; a.y_stride = y_row_stride; a.workspace = nullptr; a.workspace_bytes = 0;
+    return PQ_OK;
+}
+
+int pq_gemm(const void *x, int32_t T, int64_t x_row_stride, const void *codes, const void *codebooks,
+            const void *scales, const void *bias, const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G,
+            int32_t M, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype, void *y, int64_t y_row_stride,
+            void *workspace, size_t workspace_bytes, void *stream) {
+    pq::GemmArgs a;
+    int rc = fill_gemm(a, "pq_gemm", x, T, x_row_stride, codes, codebooks, scales, bias, part_sizes, num_parts, N, G,
+                       M, K, d, code_bytes, dtype, y, y_row_stride);
+    if (rc) return rc;
+    if (T == 0 || N == 0) return PQ_OK;
+    if (!y || !scales) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_gemm: NULL tensor pointer");
+    if (G > 0 && (!x || !codes || !codebooks)) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_gemm: NULL tensor pointer");
+    a.workspace = workspace;
+    a.workspace_bytes = workspace_bytes;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    switch (choose(a)) {
+    case K_TILED: e = pq::launch_gemm_tiled(a, s); break;
+    case K_STREAM: e = pq::launch_gemm_stream(a, s); break;
+    default: e = pq::launch_gemm_generic(a, s); break;
+    }
+    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "pq_gemm: %s", hipGetErrorString(e));
+    return PQ_OK;
+}
+
+int pq_gemm_kernel_name(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes,
+                        int32_t dtype, const int32_t *part_sizes, int32_t num_parts, char *buf, size_t buf_len) {
+    pq::GemmArgs a;
+    // aligned dummy pointers: the choice depends on alignment, which real tensors from an allocator have
+    void *al = reinterpret_cast<void *>(uintptr_t(256));
+    int rc = fill_gemm(a, "pq_gemm_kernel_name", al, T, (int64_t)G * d, al, al, al, nullptr, part_sizes, num_parts, N,
+                       G, M, K, d, code_bytes, dtype, al, N);
+    if (rc) return rc;
+    if (!buf || buf_len == 0) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_gemm_kernel_name: no buffer");
+    static const char *names[] = {"generic", "mfma_stream", "mfma_tiled"};
+    snprintf(buf, buf_len, "%s", names[choose(a)]);
+    return PQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// Shared device helpers for the gfx950 PQ kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pq_amd.h"
+
+namespace pq {
+
+typedef __bf16 bf16_t;
+typedef _Float16 fp16_t;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fp16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// Output-partition table, passed by value.  Rows [start[p], start[p] + size[p]) use codebooks
+// p*M .. p*M+M-1  (generic_dequantize_gemm's narrow() calls, aqlm.py:115-126).
+struct Parts {
+    int num;
+    int size[PQ_MAX_PARTS];
+};
+
+// Maps a tile index to (partition, first row, row count) when every partition is cut into tiles of
+// `rows_per_tile` rows separately, so that no tile straddles two codebooks.
+struct TileLoc {
+    int part;
+    int row0;   // absolute first row
+    int nrows;  // rows in this tile (<= rows_per_tile)
+};
+
+__host__ __device__ inline int tiles_in(const Parts &P, int rows_per_tile) {
+    int t = 0;
+    for (int p = 0; p < P.num; ++p) t += (P.size[p] + rows_per_tile - 1) / rows_per_tile;
+    return t;
+}
+
+__device__ inline TileLoc locate_tile(const Parts &P, int tile, int rows_per_tile) {
+    TileLoc L;
+    int row = 0;
+    L.part = 0;
+    L.row0 = 0;
+    L.nrows = 0;
+#pragma unroll
+    for (int p = 0; p < PQ_MAX_PARTS; ++p) {
+        if (p < P.num) {
+            const int nt = (P.size[p] + rows_per_tile - 1) / rows_per_tile;
+            if (tile >= 0 && tile < nt) {
+                L.part = p;
+                L.row0 = row + tile * rows_per_tile;
+                const int left = P.size[p] - tile * rows_per_tile;
+                L.nrows = left < rows_per_tile ? left : rows_per_tile;
+                tile = -1;
+            } else if (tile >= nt) {
+                tile -= nt;
+            }
+            row += P.size[p];
+        }
+    }
+    return L;
+}
+
+// ---- act dtype traits ---------------------------------------------------------------------
+template <typename AT>
+struct Act;
+template <>
+struct Act<bf16_t> {
+    typedef bf16x8 vec8;
+    static __device__ inline float to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+    static __device__ inline uint16_t from_f32(float f) {
+        bf16_t b = (bf16_t)f;  // v_cvt_pk_bf16_f32: nearest even, NaN stays NaN
+        return __builtin_bit_cast(uint16_t, b);
+    }
+    // element-wise a + b, each sum rounded once to bf16 (nearest even)
+    static __device__ inline vec8 add8(vec8 a, vec8 b) {
+        vec8 r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (bf16_t)((float)a[i] + (float)b[i]);
+        return r;
+    }
+    static __device__ inline f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ inline f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct Act<fp16_t> {
+    typedef fp16x8 vec8;
+    static __device__ inline float to_f32(uint16_t h) { return (float)__builtin_bit_cast(fp16_t, h); }
+    static __device__ inline uint16_t from_f32(float f) {
+        fp16_t b = (fp16_t)f;
+        return __builtin_bit_cast(uint16_t, b);
+    }
+    static __device__ inline vec8 add8(vec8 a, vec8 b) { return a + b; }   // v_pk_add_f16: correctly rounded
+    static __device__ inline f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ inline f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// Unsigned index of a signed stored code: value mod K with K a power of two (aqlm.py:32-34).
+template <typename CodeT>
+__device__ inline uint32_t code_index(CodeT c, uint32_t kmask) {
+    return (uint32_t)(int32_t)c & kmask;
+}
+
+}  // namespace pq

@@ -1,0 +1,169 @@
+// Dense-weight reconstruction (codebook gather) for gfx950.
+//
+// W[n][g*d + j] = sum_m codebooks[p(n)*M + m][ codes[n][g][m] mod K ][j]   (* scales[n])
+//
+// HBM-bound on the output stream (N*Kin*2 B written against N*G*M*code_bytes read): each thread
+// produces one 16-byte piece of an output row per step, so a wave writes 1 KiB contiguous; the
+// codebooks of the tile's partition sit in LDS when they fit (M*K*d*2 B <= 64 KiB), else they are
+// gathered from L2.
+#include "pq_common.cuh"
+#include "pq_kernels.h"
+
+namespace pq {
+
+constexpr int DQ_THREADS = 256;
+constexpr int DQ_ROWS = 8;                 // rows per tile
+constexpr int DQ_LDS_BYTES = 64 * 1024;    // codebook budget
+
+// D = sub-vector length in elements, restricted to divisors of 8 so that one thread's 8 output
+// elements are 8/D whole groups.  USE_LDS: codebooks staged in LDS.
+template <typename AT, typename CodeT, int D, bool USE_LDS>
+__global__ __launch_bounds__(DQ_THREADS) void dequant_vec8_kernel(
+    const CodeT *__restrict__ codes, const uint16_t *__restrict__ codebooks, const uint16_t *__restrict__ scales,
+    Parts parts, int G, int M, int K, uint16_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *cb_lds = reinterpret_cast<uint16_t *>(smem);
+
+    const TileLoc loc = locate_tile(parts, blockIdx.x, DQ_ROWS);
+    const int Kin = G * D;
+    const uint32_t kmask = (uint32_t)K - 1u;
+    const uint16_t *cb_g = codebooks + (size_t)loc.part * M * K * D;
+
+    if (USE_LDS) {
+        const int n16 = (M * K * D * 2) / 16;  // M*K*D*2 is a multiple of 16 for K >= 8/D ... checked on the host
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(cb_g);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(cb_lds);
+        for (int i = threadIdx.x; i < n16; i += DQ_THREADS) dst[i] = src[i];
+        __syncthreads();
+    }
+    const uint16_t *cb = USE_LDS ? cb_lds : cb_g;
+
+    constexpr int GPT = 8 / D;            // groups per thread-step
+    const int pieces_per_row = Kin / 8;   // 16-byte pieces
+    const int total = loc.nrows * pieces_per_row;
+    for (int i = threadIdx.x; i < total; i += DQ_THREADS) {
+        const int r = i / pieces_per_row;
+        const int c = i - r * pieces_per_row;
+        const int n = loc.row0 + r;
+        const CodeT *crow = codes + ((size_t)n * G + (size_t)c * GPT) * M;
+        uint16_t h[8];
+        if (M == 1) {
+#pragma unroll
+            for (int gg = 0; gg < GPT; ++gg) {
+                const uint32_t idx = code_index(crow[gg], kmask);
+                const uint16_t *e = cb + (size_t)idx * D;
+#pragma unroll
+                for (int j = 0; j < D; ++j) h[gg * D + j] = e[j];
+            }
+        } else {
+#pragma unroll
+            for (int gg = 0; gg < GPT; ++gg) {
+                float acc[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) acc[j] = 0.f;
+                for (int m = 0; m < M; ++m) {
+                    const uint32_t idx = code_index(crow[gg * M + m], kmask);
+                    const uint16_t *e = cb + ((size_t)m * K + idx) * D;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) acc[j] += Act<AT>::to_f32(e[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < D; ++j) h[gg * D + j] = Act<AT>::from_f32(acc[j]);
+            }
+        }
+        if (scales) {
+            const float s = Act<AT>::to_f32(scales[n]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = Act<AT>::from_f32(Act<AT>::to_f32(h[j]) * s);
+        }
+        u32x4 v;
+        v.x = h[0] | ((uint32_t)h[1] << 16);
+        v.y = h[2] | ((uint32_t)h[3] << 16);
+        v.z = h[4] | ((uint32_t)h[5] << 16);
+        v.w = h[6] | ((uint32_t)h[7] << 16);
+        *reinterpret_cast<u32x4 *>(out + (size_t)n * Kin + (size_t)c * 8) = v;
+    }
+}
+
+// Any d, any Kin: one output element per thread-step.
+template <typename AT, typename CodeT>
+__global__ __launch_bounds__(DQ_THREADS) void dequant_elem_kernel(
+    const CodeT *__restrict__ codes, const uint16_t *__restrict__ codebooks, const uint16_t *__restrict__ scales,
+    Parts parts, int G, int M, int K, int d, uint16_t *__restrict__ out) {
+    const TileLoc loc = locate_tile(parts, blockIdx.x, DQ_ROWS);
+    const int Kin = G * d;
+    const uint32_t kmask = (uint32_t)K - 1u;
+    const uint16_t *cb = codebooks + (size_t)loc.part * M * K * d;
+    const int total = loc.nrows * Kin;
+    for (int i = threadIdx.x; i < total; i += DQ_THREADS) {
+        const int r = i / Kin;
+        const int k = i - r * Kin;
+        const int g = k / d;
+        const int j = k - g * d;
+        const int n = loc.row0 + r;
+        const CodeT *crow = codes + ((size_t)n * G + g) * M;
+        uint16_t h;
+        if (M == 1) {
+            h = cb[(size_t)code_index(crow[0], kmask) * d + j];
+        } else {
+            float acc = 0.f;
+            for (int m = 0; m < M; ++m)
+                acc += Act<AT>::to_f32(cb[((size_t)m * K + code_index(crow[m], kmask)) * d + j]);
+            h = Act<AT>::from_f32(acc);
+        }
+        if (scales) h = Act<AT>::from_f32(Act<AT>::to_f32(h) * Act<AT>::to_f32(scales[n]));
+        out[(size_t)n * Kin + k] = h;
+    }
+}
+
+template <typename AT, typename CodeT>
+static hipError_t launch_dequant_t(const DequantArgs &a, hipStream_t stream) {
+    const int tiles = tiles_in(a.parts, DQ_ROWS);
+    if (tiles == 0) return hipSuccess;
+    const CodeT *codes = static_cast<const CodeT *>(a.codes);
+    const uint16_t *cb = static_cast<const uint16_t *>(a.codebooks);
+    const uint16_t *sc = static_cast<const uint16_t *>(a.scales);
+    uint16_t *out = static_cast<uint16_t *>(a.out);
+    const size_t cb_bytes = (size_t)a.M * a.K * a.d * 2;
+    const bool vec_ok = (a.d == 1 || a.d == 2 || a.d == 4 || a.d == 8) && ((a.G * a.d) % 8 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (!vec_ok) {
+        hipLaunchKernelGGL((dequant_elem_kernel<AT, CodeT>), dim3(tiles), dim3(DQ_THREADS), 0, stream, codes, cb, sc,
+                           a.parts, a.G, a.M, a.K, a.d, out);
+        return hipGetLastError();
+    }
+    const bool use_lds = cb_bytes <= (size_t)DQ_LDS_BYTES && (cb_bytes % 16 == 0) &&
+                         ((reinterpret_cast<uintptr_t>(cb) & 15) == 0);
+    const size_t lds = use_lds ? cb_bytes : 0;
+#define PQ_DQ_LAUNCH(DD, LL)                                                                                    \
+    hipLaunchKernelGGL((dequant_vec8_kernel<AT, CodeT, DD, LL>), dim3(tiles), dim3(DQ_THREADS), lds, stream, codes, \
+                       cb, sc, a.parts, a.G, a.M, a.K, out)
+    if (use_lds) {
+        switch (a.d) {
+        case 1: PQ_DQ_LAUNCH(1, true); break;
+        case 2: PQ_DQ_LAUNCH(2, true); break;
+        case 4: PQ_DQ_LAUNCH(4, true); break;
+        default: PQ_DQ_LAUNCH(8, true); break;
+        }
+    } else {
+        switch (a.d) {
+        case 1: PQ_DQ_LAUNCH(1, false); break;
+        case 2: PQ_DQ_LAUNCH(2, false); break;
+        case 4: PQ_DQ_LAUNCH(4, false); break;
+        default: PQ_DQ_LAUNCH(8, false); break;
+        }
+    }
+#undef PQ_DQ_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_dequant(const DequantArgs &a, hipStream_t stream) {
+    if (a.dtype == PQ_DTYPE_BF16) {
+        return a.code_bytes == 1 ? launch_dequant_t<bf16_t, int8_t>(a, stream)
+                                 : launch_dequant_t<bf16_t, int16_t>(a, stream);
+    }
+    return a.code_bytes == 1 ? launch_dequant_t<fp16_t, int8_t>(a, stream)
+                             : launch_dequant_t<fp16_t, int16_t>(a, stream);
+}
+
+}  // namespace pq

@@ -1,0 +1,49 @@
+// Internal launch interface between the C ABI (pq_api.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "pq_common.cuh"
+
+namespace pq {
+
+struct DequantArgs {
+    const void *codes;
+    const void *codebooks;
+    const void *scales;  // nullable
+    Parts parts;
+    int N, G, M, K, d, code_bytes, dtype;
+    void *out;
+};
+
+struct GemmArgs {
+    const void *x;
+    int T;
+    int64_t x_stride;
+    const void *codes;
+    const void *codebooks;
+    const void *scales;
+    const void *bias;  // nullable
+    Parts parts;
+    int N, G, M, K, d, code_bytes, dtype;
+    void *y;
+    int64_t y_stride;
+    void *workspace;
+    size_t workspace_bytes;
+};
+
+hipError_t launch_dequant(const DequantArgs &a, hipStream_t stream);
+
+// Any format: one wave per output row, VALU dot products.  Always available.
+hipError_t launch_gemm_generic(const GemmArgs &a, hipStream_t stream);
+
+// Fused gather + MFMA, weight-streaming (small T).  supported() says whether the format fits.
+bool gemm_stream_supported(const GemmArgs &a);
+hipError_t launch_gemm_stream(const GemmArgs &a, hipStream_t stream);
+
+// Fused gather + MFMA, LDS-tiled activations (large T).
+bool gemm_tiled_supported(const GemmArgs &a);
+hipError_t launch_gemm_tiled(const GemmArgs &a, hipStream_t stream);
+
+}  // namespace pq

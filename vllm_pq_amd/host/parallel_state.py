@@ -1,0 +1,76 @@
+"""Tensor-parallel group of the stand-alone host mirror: one process per GPU over
+torch.distributed ("nccl" is RCCL on ROCm; "gloo" for CPU tests).
+
+Mirrors what the linear layers need from vllm/distributed: get_tensor_model_parallel_rank /
+_world_size, tensor_model_parallel_all_reduce / _all_gather (communication_op.py:11-19), divide and
+split_tensor_along_last_dim (distributed/utils.py).  World size 1 bypasses every collective
+(parallel_state.py:303).
+"""
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+_TP_GROUP: Optional["dist.ProcessGroup"] = None
+_TP_RANK = 0
+_TP_SIZE = 1
+
+
+def initialize_model_parallel(tensor_model_parallel_size: Optional[int] = None,
+                              group: Optional["dist.ProcessGroup"] = None) -> None:
+    """Use the whole default process group (or `group`) as the TP group."""
+    global _TP_GROUP, _TP_RANK, _TP_SIZE
+    if not dist.is_initialized():
+        if tensor_model_parallel_size not in (None, 1):
+            raise RuntimeError("torch.distributed is not initialised")
+        _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
+        return
+    g = group if group is not None else dist.group.WORLD
+    size = dist.get_world_size(g)
+    if tensor_model_parallel_size is not None and tensor_model_parallel_size != size:
+        raise ValueError(f"tensor_model_parallel_size={tensor_model_parallel_size} != group size {size}")
+    _TP_GROUP, _TP_RANK, _TP_SIZE = g, dist.get_rank(g), size
+
+
+def destroy_model_parallel() -> None:
+    global _TP_GROUP, _TP_RANK, _TP_SIZE
+    _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
+
+
+def get_tensor_model_parallel_rank() -> int:
+    return _TP_RANK
+
+
+def get_tensor_model_parallel_world_size() -> int:
+    return _TP_SIZE
+
+
+def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
+    """Out-of-place SUM over the TP group (RowParallelLinear.forward, linear.py:1212-1213)."""
+    if _TP_SIZE == 1:
+        return input_
+    out = input_.clone()
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=_TP_GROUP)
+    return out
+
+
+def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """Concatenate the ranks' tensors along `dim` (ColumnParallelLinear gather_output, linear.py:426-428)."""
+    if _TP_SIZE == 1:
+        return input_
+    if dim < 0:
+        dim += input_.dim()
+    parts = [torch.empty_like(input_) for _ in range(_TP_SIZE)]
+    dist.all_gather(parts, input_.contiguous(), group=_TP_GROUP)
+    return torch.cat(parts, dim=dim)
+
+
+def divide(numerator: int, denominator: int) -> int:
+    if numerator % denominator != 0:
+        raise AssertionError(f"{numerator} is not divisible by {denominator}")
+    return numerator // denominator
+
+
+def split_tensor_along_last_dim(tensor: torch.Tensor, num_partitions: int) -> Sequence[torch.Tensor]:
+    size = divide(tensor.shape[-1], num_partitions)
+    return torch.split(tensor, size, dim=-1)

@@ -1,0 +1,178 @@
+"""Operator layer of the PQ linear path: thin wrappers over the C ABI, registered as torch custom
+ops with fake (meta) implementations so that torch.compile / graph capture can trace them.
+
+Call-compatible with the reference's wrappers for its codebook kernels
+(vllm/_custom_ops.py:347-371 fake impls, :646-658 wrappers):
+    pq_gemm(input, codes, codebooks, scales, codebook_partition_sizes, bias)   <-> ops.aqlm_gemm
+    pq_dequant(codes, codebooks, codebook_partition_sizes)                     <-> ops.aqlm_dequant
+Unlike the reference's ops these accept every sub-vector length / codebook size / dtype of the
+format (the reference's kernels take d == 8 with (K, M) in {(65536, 1), (256, 2)} and fp16 only,
+csrc/quantization/aqlm/gemm_kernels.cu:519-542) and in_features is G * d rather than G * 8.
+
+Tensors must live on a ROCm device; anything else raises.
+"""
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+_DTYPE = {torch.float16: _lib.PQ_DTYPE_FP16, torch.bfloat16: _lib.PQ_DTYPE_BF16}
+_CODE_BYTES = {torch.int8: 1, torch.int16: 2}
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _check_device(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                f"vllm_pq_amd ops run on MI355X only: got a tensor on '{t.device}'. There is no CPU fallback.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"vllm_pq_amd: tensors on different devices ({dev} vs {t.device})")
+    return dev
+
+
+def _format(codes: torch.Tensor, codebooks: torch.Tensor, partition_sizes):
+    if codes.dim() != 3:
+        raise ValueError(f"codes must be [out_features, in_groups, num_codebooks], got {tuple(codes.shape)}")
+    if codebooks.dim() != 4 or codebooks.shape[2] != 1:
+        raise ValueError(f"codebooks must be [P*M, K, 1, d] (out_group_size 1), got {tuple(codebooks.shape)}")
+    if codes.dtype not in _CODE_BYTES:
+        raise ValueError(f"codes dtype {codes.dtype}: int8 and int16 are supported")
+    if codebooks.dtype not in _DTYPE:
+        raise ValueError(f"codebooks dtype {codebooks.dtype}: fp16 and bf16 are supported")
+    N, G, M = codes.shape
+    parts = [int(s) for s in partition_sizes] if len(partition_sizes) else [N]
+    P = len(parts)
+    if codebooks.shape[0] != P * M:
+        raise ValueError(f"codebooks.shape[0]={codebooks.shape[0]} != partitions*num_codebooks={P}*{M}")
+    K, d = codebooks.shape[1], codebooks.shape[3]
+    return N, G, M, K, d, parts
+
+
+def _raise(rc: int):
+    msg = _lib.last_error()
+    if rc in (1, 2):
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+# ---- eager implementations ------------------------------------------------------------------
+def _pq_dequant_impl(codes: torch.Tensor, codebooks: torch.Tensor, codebook_partition_sizes: List[int],
+                     scales: Optional[torch.Tensor] = None) -> torch.Tensor:
+    L = _lib.load()
+    dev = _check_device(codes, codebooks, scales)
+    N, G, M, K, d, parts = _format(codes, codebooks, codebook_partition_sizes)
+    codes = codes.contiguous()
+    codebooks = codebooks.contiguous()
+    if scales is not None:
+        if scales.numel() != N or scales.dtype != codebooks.dtype:
+            raise ValueError("scales must hold one value of the codebooks' dtype per output row")
+        scales = scales.contiguous()
+    out = torch.empty((N, G * d), dtype=codebooks.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.pq_dequant(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr() if scales is not None else None,
+                          _lib.parts_array(parts), len(parts), N, G, M, K, d, _CODE_BYTES[codes.dtype],
+                          _DTYPE[codebooks.dtype], out.data_ptr(), _stream_ptr(dev))
+    if rc:
+        _raise(rc)
+    return out
+
+
+def _pq_gemm_impl(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor,
+                  codebook_partition_sizes: List[int], bias: Optional[torch.Tensor]) -> torch.Tensor:
+    L = _lib.load()
+    dev = _check_device(input, codes, codebooks, scales, bias)
+    N, G, M, K, d, parts = _format(codes, codebooks, codebook_partition_sizes)
+    if input.dtype != codebooks.dtype:
+        raise ValueError(f"input dtype {input.dtype} != codebooks dtype {codebooks.dtype}")
+    if input.shape[-1] != G * d:
+        raise ValueError(f"input has {input.shape[-1]} features, the weight expects {G * d}")
+    if scales.numel() != N or scales.dtype != input.dtype:
+        raise ValueError("scales must hold one value of the activation dtype per output row")
+    if bias is not None and (bias.numel() != N or bias.dtype != input.dtype):
+        raise ValueError("bias must hold one value of the activation dtype per output row")
+    x2 = input.reshape(-1, input.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    T = x2.shape[0]
+    codes = codes.contiguous()
+    codebooks = codebooks.contiguous()
+    scales = scales.contiguous()
+    if bias is not None:
+        bias = bias.contiguous()
+    out = torch.empty((T, N), dtype=input.dtype, device=dev)
+    if T and N:
+        with torch.cuda.device(dev):
+            rc = L.pq_gemm(x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, codes.data_ptr(),
+                           codebooks.data_ptr(), scales.data_ptr(), bias.data_ptr() if bias is not None else None,
+                           _lib.parts_array(parts), len(parts), N, G, M, K, d, _CODE_BYTES[codes.dtype],
+                           _DTYPE[input.dtype], out.data_ptr(), N, None, 0, _stream_ptr(dev))
+        if rc:
+            _raise(rc)
+    return out.reshape(input.shape[:-1] + (N,))
+
+
+# ---- torch custom ops (schema + fake impl), as the reference registers its ops ----------------
+_HAVE_CUSTOM_OP = hasattr(torch, "library") and hasattr(torch.library, "custom_op")
+
+if _HAVE_CUSTOM_OP:
+
+    @torch.library.custom_op("pq_amd::gemm", mutates_args=(), device_types="cuda")
+    def _gemm_op(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor,
+                 codebook_partition_sizes: List[int], bias: Optional[torch.Tensor]) -> torch.Tensor:
+        return _pq_gemm_impl(input, codes, codebooks, scales, codebook_partition_sizes, bias)
+
+    @_gemm_op.register_fake
+    def _gemm_fake(input, codes, codebooks, scales, codebook_partition_sizes, bias):
+        return input.new_empty(input.shape[:-1] + (codes.shape[0],))
+
+    @torch.library.custom_op("pq_amd::dequant", mutates_args=(), device_types="cuda")
+    def _dequant_op(codes: torch.Tensor, codebooks: torch.Tensor, codebook_partition_sizes: List[int],
+                    scales: Optional[torch.Tensor]) -> torch.Tensor:
+        return _pq_dequant_impl(codes, codebooks, codebook_partition_sizes, scales)
+
+    @_dequant_op.register_fake
+    def _dequant_fake(codes, codebooks, codebook_partition_sizes, scales):
+        return codebooks.new_empty((codes.shape[0], codes.shape[1] * codebooks.shape[3]))
+
+
+def pq_gemm(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor,
+            codebook_partition_sizes: List[int], bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """y = input @ W^T (+ bias): W is decoded on the fly from codes/codebooks/scales.
+    Same signature as ops.aqlm_gemm (vllm/_custom_ops.py:646-652)."""
+    if _HAVE_CUSTOM_OP and input.is_cuda:
+        return torch.ops.pq_amd.gemm(input, codes, codebooks, scales, list(codebook_partition_sizes), bias)
+    return _pq_gemm_impl(input, codes, codebooks, scales, codebook_partition_sizes, bias)
+
+
+def pq_dequant(codes: torch.Tensor, codebooks: torch.Tensor, codebook_partition_sizes: List[int],
+               scales: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Dense [out_features, in_features] weight.  With scales=None: same signature and result as
+    ops.aqlm_dequant (vllm/_custom_ops.py:655-658); with scales it is dequantize_weight per partition
+    (aqlm.py:37-74)."""
+    if _HAVE_CUSTOM_OP and codes.is_cuda:
+        return torch.ops.pq_amd.dequant(codes, codebooks, list(codebook_partition_sizes), scales)
+    return _pq_dequant_impl(codes, codebooks, codebook_partition_sizes, scales)
+
+
+def gemm_kernel_name(T: int, N: int, G: int, M: int, K: int, d: int, code_bytes: int, dtype: torch.dtype,
+                     partition_sizes) -> str:
+    """Name of the kernel pq_gemm selects for a problem (no GPU needed)."""
+    import ctypes
+    L = _lib.load()
+    buf = ctypes.create_string_buffer(64)
+    parts = [int(s) for s in partition_sizes] if len(partition_sizes) else [N]
+    rc = L.pq_gemm_kernel_name(T, N, G, M, K, d, code_bytes, _DTYPE[dtype], _lib.parts_array(parts), len(parts), buf,
+                               64)
+    if rc:
+        _raise(rc)
+    return buf.value.decode()

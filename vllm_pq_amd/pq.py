@@ -1,0 +1,171 @@
+"""PQConfig / PQLinearMethod: the product-quantised linear method behind vLLM's
+QuantizationConfig / LinearMethodBase plugin surface.
+
+The tensor format is the reference's codebook format (AQLM, num_codebooks == 1 is plain PQ with a
+per-partition codebook and a per-output-row scale):
+
+    W[o, g*d:(g+1)*d] = scales[o] * sum_m codebooks[p(o)*M + m, codes[o, g, m] mod K, 0, :]
+
+and every class / method mirrors its counterpart in
+vllm/model_executor/layers/quantization/aqlm.py:
+    get_int_dtype       :20-29     unpack_int_data     :32-34
+    PQConfig            <-> AQLMConfig :159-217
+    PQLinearMethod      <-> AQLMLinearMethod :220-374 (create_weights :230-323, apply :325-374)
+Differences, all on purpose: bf16 as well as fp16 activations; every (K, d, M) goes to the fused HIP
+kernels (the reference only accelerates d == 8 with (K, M) in {(256, 2), (65536, 1)} and falls back to
+PyTorch otherwise, aqlm.py:344-374); there is no PyTorch fallback here.
+"""
+from typing import Any, Dict, List, Optional
+
+import torch
+from torch.nn.parameter import Parameter
+
+from . import ops
+from .compat import (LinearBase, LinearMethodBase, QUANTIZATION_METHODS, QuantizationConfig,
+                     register_quantization_config, set_weight_attrs)
+
+PQ_METHOD_NAME = "pq"
+
+
+def get_int_dtype(nbits: int) -> torch.dtype:
+    """Narrowest signed storage type holding an nbits-wide code (one code per element)."""
+    for limit, dt in ((8, torch.int8), (16, torch.int16), (32, torch.int32), (64, torch.int64)):
+        if nbits <= limit:
+            return dt
+    raise ValueError(f"No dtype available for {nbits}-bit codebooks")
+
+
+@torch.inference_mode()
+def unpack_int_data(data: torch.Tensor, nbits: int) -> torch.Tensor:
+    """Signed stored codes -> unsigned indices in [0, 2**nbits)."""
+    return data.to(torch.int64) % (1 << nbits)
+
+
+class PQConfig(QuantizationConfig):
+    """Config of the PQ method.  Keys of the HF `quantization_config` dict are the reference's:
+    in_group_size (sub-vector length d), nbits_per_codebook (log2 K), num_codebooks (M, 1 = plain PQ),
+    out_group_size (must be 1)."""
+
+    def __init__(self, in_group_size: int = 8, nbits_per_codebook: int = 8, num_codebooks: int = 1,
+                 out_group_size: int = 1) -> None:
+        super().__init__()
+        self.in_group_size = int(in_group_size)
+        self.nbits_per_codebook = int(nbits_per_codebook)
+        self.num_codebooks = int(num_codebooks)
+        self.out_group_size = int(out_group_size)
+        # the reference asserts this (aqlm.py:178-179)
+        assert self.out_group_size == 1, "out_group_size > 1 is not supported"
+        if self.in_group_size < 1 or self.num_codebooks < 1 or not (1 <= self.nbits_per_codebook <= 16):
+            raise ValueError(f"unsupported PQ format: {self!r}")
+        self.pack_factor = self.in_group_size * self.out_group_size
+
+    def __repr__(self) -> str:
+        return (f"PQConfig(in_group_size={self.in_group_size}, nbits_per_codebook={self.nbits_per_codebook}, "
+                f"num_codebooks={self.num_codebooks}, out_group_size={self.out_group_size})")
+
+    @classmethod
+    def get_name(cls) -> str:
+        return PQ_METHOD_NAME
+
+    @classmethod
+    def get_supported_act_dtypes(cls) -> List[torch.dtype]:
+        return [torch.half, torch.bfloat16]
+
+    @classmethod
+    def get_min_capability(cls) -> int:
+        # gfx950 reports compute capability 9.5; the kernels use gfx950-only MFMA shapes.  Platforms
+        # without a capability (CPU) skip this gate (vllm/config.py:3333-3335).
+        return 95
+
+    @staticmethod
+    def get_config_filenames() -> List[str]:
+        return []
+
+    @classmethod
+    def from_config(cls, config: Dict[str, Any]) -> "PQConfig":
+        d = cls.get_from_keys(config, ["in_group_size", "sub_dim"])
+        if "nbits_per_codebook" in config:
+            nbits = config["nbits_per_codebook"]
+        else:
+            k = cls.get_from_keys(config, ["nbits_per_codebook", "codebook_size"])
+            if k < 2 or k & (k - 1):
+                raise ValueError(f"codebook_size={k} is not a power of two")
+            nbits = k.bit_length() - 1
+        m = cls.get_from_keys_or(config, ["num_codebooks"], 1)
+        og = cls.get_from_keys_or(config, ["out_group_size"], 1)
+        return cls(d, nbits, m, og)
+
+    def get_quant_method(self, layer: torch.nn.Module, prefix: str) -> Optional["PQLinearMethod"]:
+        if isinstance(layer, LinearBase):
+            return PQLinearMethod(self)
+        return None
+
+
+class PQLinearMethod(LinearMethodBase):
+    """Linear method for PQ-compressed weights."""
+
+    def __init__(self, quant_config: PQConfig):
+        self.quant_config = quant_config
+
+    def create_weights(self, layer: torch.nn.Module, input_size_per_partition: int,
+                       output_partition_sizes: List[int], input_size: int, output_size: int,
+                       params_dtype: torch.dtype, **extra_weight_attrs):
+        del input_size, output_size
+        cfg = self.quant_config
+        if params_dtype not in (torch.half, torch.bfloat16):
+            raise ValueError("Only half and bfloat16 are currently supported by pq")
+        if input_size_per_partition % cfg.in_group_size != 0:
+            raise ValueError("The input size is not aligned with the quantized weight shape. "
+                             "This can be caused by too large tensor parallel size.")
+        n_out = sum(output_partition_sizes)
+        if n_out % cfg.out_group_size != 0:
+            raise ValueError("The output size is not aligned with the quantized weight shape. "
+                             "This can be caused by too large tensor parallel size.")
+
+        # [out, in_groups, M] signed codes; rows shard along dim 0 (column parallel), groups along
+        # dim 1 (row parallel); packed_dim/pack_factor let the fused-layer loaders convert offsets.
+        codes = Parameter(torch.empty(n_out, input_size_per_partition // cfg.pack_factor, cfg.num_codebooks,
+                                      dtype=get_int_dtype(cfg.nbits_per_codebook)), requires_grad=False)
+        set_weight_attrs(codes, {"input_dim": 1, "output_dim": 0, "packed_dim": 1, "pack_factor": cfg.pack_factor})
+
+        # one block of M codebooks per logical matrix, replicated on every rank
+        codebooks = Parameter(torch.empty(cfg.num_codebooks * len(output_partition_sizes),
+                                          2 ** cfg.nbits_per_codebook, cfg.out_group_size, cfg.in_group_size,
+                                          dtype=params_dtype), requires_grad=False)
+        set_weight_attrs(codebooks, {"is_metadata": True, "output_partition_sizes": list(output_partition_sizes)})
+
+        scales = Parameter(torch.empty((n_out // cfg.out_group_size, 1, 1, 1), dtype=params_dtype),
+                           requires_grad=False)
+        set_weight_attrs(scales, {"output_dim": 0, "packed_dim": 0, "pack_factor": cfg.out_group_size})
+
+        for name, p in (("codes", codes), ("codebooks", codebooks), ("scales", scales)):
+            layer.register_parameter(name, p)
+            set_weight_attrs(p, extra_weight_attrs)
+
+    def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
+        # The kernels read the reference layout directly; only make sure the tensors are dense.
+        # Integer codes left uninitialised by a dummy load are valid indices as they are
+        # (index = value mod K).
+        for name in ("codes", "codebooks", "scales"):
+            p = getattr(layer, name)
+            if not p.data.is_contiguous():
+                p.data = p.data.contiguous()
+
+    def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        codebooks = layer.codebooks
+        parts = getattr(codebooks, "output_partition_sizes", [])
+        return ops.pq_gemm(x, layer.codes, codebooks, layer.scales, parts, bias)
+
+
+def register() -> None:
+    """Idempotent registration of the "pq" method (entry point for vLLM's `vllm.general_plugins`
+    group, which runs in every engine and worker process).  Also adds the name to the ROCm
+    platform's allow-list, which otherwise rejects unknown methods (vllm/platforms/rocm.py:108-111)."""
+    if PQ_METHOD_NAME not in QUANTIZATION_METHODS:
+        register_quantization_config(PQ_METHOD_NAME)(PQConfig)
+    try:  # pragma: no cover - needs vLLM
+        from vllm.platforms.rocm import RocmPlatform
+        if PQ_METHOD_NAME not in RocmPlatform.supported_quantization:
+            RocmPlatform.supported_quantization.append(PQ_METHOD_NAME)
+    except Exception:
+        pass
