@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Benchmark of the PQ linear hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): the PQ-quantised linear layers of Llama-3-8B -- qkv_proj,
+o_proj, gate_up_proj, down_proj of all 32 decoder layers, K=256, sub-dim 8, one codebook per output
+partition, bf16 activations -- called through PQLinearMethod.apply() behind the tensor-parallel linear
+layers.  One step = one pass of a batch of `--tokens` synthetic tokens through those 128 apply() calls
+(every layer has its own weights: 832 MiB of codes, more than the 256 MiB Infinity Cache, so codes
+stream from HBM).  With --gpus N the layers are sharded column/row-parallel over N ranks (TP=N) and
+every row-parallel output is summed with an RCCL all-reduce; total work is fixed ("strong" scaling).
+
+Prints ONE JSON line on rank 0.  `value` = effective TFLOP/s of the whole job,
+2*T*sum(N*Kin) / step time; `hbm_gbps` and `tokens_per_s` are the same measurement in the metric's
+other two units.  `roofline` is for the dominant kernel (gate_up_proj), timed with HIP events on the
+launch stream; `cpu_baseline` times the torch-CPU restatement of the reference's CPU algorithm
+(oracle/torch_restatement.py) on a bounded sample on this box's host cores; `decode` repeats the
+step measurement at a small token count (HBM-bound regime).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/fp16 MFMA spec
+
+LLAMA3_8B = dict(hidden=4096, inter=14336, heads=32, kv_heads=8, head_dim=128, layers=32)
+K_ENTRIES, SUB_DIM, NUM_CODEBOOKS = 256, 8, 1
+
+
+def algorithmic_bytes(T, N, Kin, P, K=K_ENTRIES, d=SUB_DIM, M=NUM_CODEBOOKS, bias=False):
+    """Bytes one apply() must move: codes + codebooks + scales + x + y (+ bias)."""
+    cb = 1 if K <= 256 else 2
+    e = 2
+    return N * (Kin // d) * M * cb + P * M * K * d * e + N * e + T * Kin * e + T * N * e + (N * e if bias else 0)
+
+
+def build_stack(tp_size, device, dtype, cfg=LLAMA3_8B, layers=None):
+    """The four PQ linears of every decoder layer, through the plugin surface."""
+    from vllm_pq_amd import PQConfig
+    from vllm_pq_amd.host.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+    qc = PQConfig(SUB_DIM, K_ENTRIES.bit_length() - 1, NUM_CODEBOOKS, 1)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    stack = []
+    for _ in range(layers if layers is not None else cfg["layers"]):
+        block = {
+            "qkv_proj": QKVParallelLinear(cfg["hidden"], cfg["head_dim"], cfg["heads"], cfg["kv_heads"], bias=False,
+                                          params_dtype=dtype, quant_config=qc),
+            "o_proj": RowParallelLinear(cfg["heads"] * cfg["head_dim"], cfg["hidden"], bias=False,
+                                        params_dtype=dtype, quant_config=qc),
+            "gate_up_proj": MergedColumnParallelLinear(cfg["hidden"], [cfg["inter"]] * 2, bias=False,
+                                                       params_dtype=dtype, quant_config=qc),
+            "down_proj": RowParallelLinear(cfg["inter"], cfg["hidden"], bias=False, params_dtype=dtype,
+                                           quant_config=qc),
+        }
+        for layer in block.values():
+            layer.codes.data = torch.randint(-128, 128, layer.codes.shape, generator=g, dtype=torch.int8)
+            layer.codebooks.data = torch.randn(layer.codebooks.shape, generator=g).to(dtype)
+            layer.scales.data = (torch.rand(layer.scales.shape, generator=g) + 0.5).to(dtype)
+            layer.to(device)
+            layer.quant_method.process_weights_after_loading(layer)
+        stack.append(block)
+    return stack
+
+
+def shapes_of(block):
+    """(name, N_rank, Kin_rank, P) per linear of one decoder layer on this rank."""
+    out = []
+    for name, layer in block.items():
+        N, G, _ = layer.codes.shape
+        out.append((name, N, G * SUB_DIM, len(layer.codebooks.output_partition_sizes)))
+    return out
+
+
+def make_inputs(block, T, device, dtype):
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    return {name: torch.randn(T, layer.codes.shape[1] * SUB_DIM, generator=g).to(dtype).to(device)
+            for name, layer in block.items()}
+
+
+def run_step(stack, inputs):
+    out = None
+    for block in stack:
+        for name, layer in block.items():
+            out, _ = layer(inputs[name])
+    return out
+
+
+class StepRunner:
+    """Runs the step eagerly or, when capture works, as one HIP graph replay (as vLLM does for decode)."""
+
+    def __init__(self, stack, inputs, use_graph):
+        self.stack, self.inputs, self.graph = stack, inputs, None
+        if use_graph:
+            try:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    run_step(stack, inputs)
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.out = run_step(stack, inputs)
+                self.graph = g
+            except Exception as e:  # capture unsupported (e.g. a collective): fall back to eager launches
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                self.graph = None
+                torch.cuda.synchronize()
+
+    def __call__(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            run_step(self.stack, self.inputs)
+
+
+def timed_steps(runner, steps, warmup, dist_on):
+    import torch.distributed as dist
+    for _ in range(warmup):
+        runner()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def time_dominant_kernel(stack, inputs, name, reps):
+    """Average duration of one launch of the dominant linear's kernel: `reps` back-to-back launches over
+    the layers' distinct weights between two HIP events on the launch stream (no collectives)."""
+    layers = [b[name] for b in stack]
+    x = inputs[name]
+    qm = layers[0].quant_method
+    for l in layers[:4]:
+        qm.apply(l, x)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):        # graph replay: back-to-back launches without host gaps
+        for i in range(reps):
+            qm.apply(layers[i % len(layers)], x)
+    g.replay()
+    torch.cuda.synchronize()
+    e0.record(stream)
+    g.replay()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def cpu_baseline(T, dtype, budget_s=20.0):
+    """The reference's CPU algorithm (torch-CPU restatement) on one decoder layer's four linears."""
+    from oracle.torch_restatement import pq_linear_cpu
+    cfg = LLAMA3_8B
+    q, kv = cfg["heads"] * cfg["head_dim"], cfg["kv_heads"] * cfg["head_dim"]
+    lin = [("qkv_proj", [q, kv, kv], cfg["hidden"]), ("o_proj", [cfg["hidden"]], q),
+           ("gate_up_proj", [cfg["inter"]] * 2, cfg["hidden"]), ("down_proj", [cfg["hidden"]], cfg["inter"])]
+    g = torch.Generator().manual_seed(99)
+    cores = torch.get_num_threads()
+    flops, secs, used = 0.0, 0.0, []
+    for name, parts, kin in lin:
+        n = sum(parts)
+        codes = torch.randint(-128, 128, (n, kin // SUB_DIM, 1), generator=g, dtype=torch.int8)
+        cb = torch.randn(len(parts), K_ENTRIES, 1, SUB_DIM, generator=g).to(dtype)
+        sc = (torch.rand(n, 1, 1, 1, generator=g) + 0.5).to(dtype)
+        x = torch.randn(T, kin, generator=g).to(dtype)
+        if not used:
+            pq_linear_cpu(x[:1], codes[:64], cb[:1], sc[:64], [64], None)      # warm the operators up
+        t0 = time.perf_counter()
+        pq_linear_cpu(x, codes, cb, sc, parts, None)
+        dt = time.perf_counter() - t0
+        secs += dt
+        flops += 2.0 * T * n * kin
+        used.append(name)
+        if secs > budget_s:
+            break
+    return {"value": flops / secs / 1e12, "unit": "TFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"one call each of {'+'.join(used)} of one Llama-3-8B decoder layer at T={T} "
+                      f"({secs:.1f} s of CPU work), torch-CPU restatement of generic_dequantize_gemm"}
+
+
+def measure(stack, T, steps, warmup, device, dtype, world, dist_on, use_graph):
+    inputs = make_inputs(stack[0], T, device, dtype)
+    runner = StepRunner(stack, inputs, use_graph)
+    dt = timed_steps(runner, steps, warmup, dist_on)
+    per_step = dt / steps
+    # whole-job work: the unsharded model's FLOPs; bytes: what all ranks must move
+    flops = sum(2.0 * T * n * kin for (_, n, kin, _) in shapes_of(stack[0])) * len(stack) * world
+    byts = sum(algorithmic_bytes(T, n, kin, p) for (_, n, kin, p) in shapes_of(stack[0])) * len(stack) * world
+    return dict(per_step=per_step, tflops=flops / per_step / 1e12, gbps=byts / per_step / 1e9,
+                tokens_per_s=T / per_step, launch="hipgraph" if runner.graph is not None else "eager",
+                inputs=inputs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tokens", type=int, default=4096, help="tokens per step (batch x seq)")
+    ap.add_argument("--decode-tokens", type=int, default=16, help="token count of the secondary decode measurement")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--layers", type=int, default=None, help="decoder layers (default: all 32)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1 or "RANK" in os.environ
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no ROCm device is visible")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
+
+    import torch.distributed as dist
+    from vllm_pq_amd.host import parallel_state
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        parallel_state.initialize_model_parallel(world)
+
+    from vllm_pq_amd import ops
+    stack = build_stack(world, device, dtype, layers=args.layers)
+    T = args.tokens
+    use_graph = not args.no_graph
+
+    main_m = measure(stack, T, args.steps, args.warmup, device, dtype, world, dist_on, use_graph)
+
+    # dominant kernel: gate_up_proj (largest share of FLOPs and of code bytes)
+    dom = "gate_up_proj"
+    _, n_d, kin_d, p_d = [s for s in shapes_of(stack[0]) if s[0] == dom][0]
+    reps = max(len(stack), 32)
+    t_k = time_dominant_kernel(stack, main_m["inputs"], dom, reps)
+    k_flops = 2.0 * T * n_d * kin_d
+    k_bytes = algorithmic_bytes(T, n_d, kin_d, p_d)
+    kname = ops.gemm_kernel_name(T, n_d, kin_d // SUB_DIM, NUM_CODEBOOKS, K_ENTRIES, SUB_DIM, 1, dtype,
+                                 stack[0][dom].codebooks.output_partition_sizes)
+    # binding roofline of that launch: whichever of HBM and MFMA takes longer at peak
+    if k_flops / (MFMA_PEAK_TFLOPS * 1e12) >= k_bytes / (HBM_PEAK_GBPS * 1e9):
+        roof = {"bound": "mfma", "achieved": k_flops / t_k / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": k_bytes / t_k / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["traffic"] = None
+    roof.update({"kernel": f"{kname}:{dom}", "launch_us": t_k * 1e6, "launches_timed": reps,
+                 "algorithmic_bytes": k_bytes, "algorithmic_flops": k_flops})
+
+    decode = None
+    if not args.no_decode and args.decode_tokens != T:
+        Td = args.decode_tokens
+        dm = measure(stack, Td, max(args.steps, 20), args.warmup, device, dtype, world, dist_on, use_graph)
+        t_kd = time_dominant_kernel(stack, dm["inputs"], dom, reps)
+        kb = algorithmic_bytes(Td, n_d, kin_d, p_d)
+        decode = {"tokens": Td, "ms_per_step": dm["per_step"] * 1e3, "tflops": dm["tflops"], "hbm_gbps": dm["gbps"],
+                  "tokens_per_s": dm["tokens_per_s"], "launch": dm["launch"],
+                  "roofline": {"bound": "hbm", "achieved": kb / t_kd / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": kb / t_kd / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                               "kernel": f"{ops.gemm_kernel_name(Td, n_d, kin_d // SUB_DIM, 1, K_ENTRIES, SUB_DIM, 1, dtype, stack[0][dom].codebooks.output_partition_sizes)}:{dom}",
+                               "launch_us": t_kd * 1e6}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(min(T, 256), dtype)
+
+    if rank == 0:
+        line = {
+            "metric": "PQ dequant+GEMM effective TFLOP/s (Llama-3-8B PQ linear stack)",
+            "value": main_m["tflops"], "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": main_m["per_step"] * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "Llama-3-8B PQ linears (qkv/o/gate_up/down x %d layers), K=256, sub-dim=8, M=1"
+                                   % len(stack),
+                       "tokens_per_step": T, "parallelism": f"tp{world}", "launch": main_m["launch"],
+                       "apply_calls_per_step": 4 * len(stack)},
+            "hbm_gbps": main_m["gbps"], "tokens_per_s": main_m["tokens_per_s"],
+            "roofline": roof, "cpu_baseline": cpu, "decode": decode,
+        }
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,3 +83,22 @@ def test_gemm_matches_reference(case):
     # fp32-accumulating variant (used for the timed CPU baseline) agrees to the same bar
     y_f = orc.gemm(*args, order=0, acc_double=False)
     assert (np.abs(orc.to_f32(y_f, dt) - yf) / scale).max() <= 1.01 * ulp
+
+
+@pytest.mark.parametrize("case", G.cases("gemm"), ids=_id)
+def test_torch_restatement_matches_reference(case):
+    """The torch-CPU restatement timed as bench.py's cpu_baseline uses the reference's operators in the
+    reference's order, so it reproduces the golden outputs bit for bit."""
+    import torch
+    from oracle.torch_restatement import pq_linear_cpu
+    from pq_testlib import bits_of, tensor_of
+    dt = case["dtype"]
+    K, d = case["K"], case["d"]
+    x = tensor_of(G.get(case, "x"), dt)
+    codes = torch.from_numpy(G.get(case, "codes"))
+    cb = tensor_of(G.get(case, "codebooks"), dt).view(-1, K, 1, d)
+    sc = tensor_of(G.get(case, "scales"), dt).view(-1, 1, 1, 1)
+    b = G.get(case, "bias")
+    b = None if b is None else tensor_of(b, dt)
+    y = pq_linear_cpu(x, codes, cb, sc, case["parts"], b)
+    assert np.array_equal(bits_of(y), G.get(case, "out"))
