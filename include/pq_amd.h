@@ -102,11 +102,36 @@ int pq_gemm(const void *x, int32_t T, int64_t x_row_stride, const void *codes, c
             int64_t y_row_stride, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
- * Which kernel pq_gemm would run for this problem: writes a short name ("mfma_stream", "mfma_tiled",
+ * Load-time re-layout of the codes into the order the MFMA kernels stream them in (one contiguous
+ * KiB per 16-row fragment and k-chunk, see vllm_pq_amd/csrc/pq_gemm_stream.hip).  It is the hook
+ * QuantizeMethodBase.process_weights_after_loading exists for
+ * (vllm/model_executor/layers/quantization/base_config.py:37-42, called from
+ * vllm/model_executor/model_loader/loader.py:157-168); the reference's AQLM method keeps the checkpoint
+ * layout, so these three entry points have no counterpart there.
+ *
+ * pq_packed_codes_bytes: size of the packed buffer, or 0 when this format cannot be packed (a
+ *   partition size that is not a multiple of 16, or a (d, K, M) the MFMA kernels do not take); the
+ *   caller then keeps using pq_gemm on the reference layout.
+ * pq_repack_codes: codes [N][G][M] -> packed (caller-allocated, 16-byte aligned, that many bytes).
+ * pq_gemm_packed: pq_gemm with `packed_codes` in place of `codes`; same results bit for bit.
+ */
+size_t pq_packed_codes_bytes(const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M,
+                             int32_t K, int32_t d, int32_t code_bytes);
+int pq_repack_codes(const void *codes, const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G,
+                    int32_t M, int32_t K, int32_t d, int32_t code_bytes, void *packed_codes, void *stream);
+int pq_gemm_packed(const void *x, int32_t T, int64_t x_row_stride, const void *packed_codes,
+                   const void *codebooks, const void *scales, const void *bias /* nullable */,
+                   const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K,
+                   int32_t d, int32_t code_bytes, int32_t dtype, void *y, int64_t y_row_stride, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+/*
+ * Which kernel pq_gemm (packed = 0) or pq_gemm_packed (packed = 1) would run for this problem: writes a short name ("mfma_stream", "mfma_tiled",
  * "generic") into buf.  For tests, benchmarks and profiles.  No reference counterpart.
  */
 int pq_gemm_kernel_name(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes,
-                        int32_t dtype, const int32_t *part_sizes, int32_t num_parts, char *buf, size_t buf_len);
+                        int32_t dtype, const int32_t *part_sizes, int32_t num_parts, int32_t packed, char *buf,
+                        size_t buf_len);
 
 #ifdef __cplusplus
 }

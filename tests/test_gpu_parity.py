@@ -115,6 +115,12 @@ SEEDED = [
     (65536, 8, 1, [64], 512, 2, "fp16", False),               # AQLM 1x16 -> generic kernel
     (256, 8, 1, [100, 60], 136, 3, "bf16", True),             # ragged -> generic kernel
     (256, 8, 1, [40, 24], 128, 70, "bf16", False),            # partial row tiles, T > 64
+    (256, 8, 1, [512, 128, 128], 1024, 300, "bf16", True),    # tiled kernel: 2 token tiles, 3 partitions
+    (256, 8, 1, [272], 576, 130, "fp16", False),              # partial row tile, K not a multiple of 512
+    (256, 4, 1, [256, 256], 768, 65, "bf16", True),
+    (16, 2, 1, [256], 512, 100, "bf16", False),
+    (4096, 8, 1, [256], 1024, 48, "fp16", True),
+    (256, 8, 2, [256], 1024, 40, "bf16", False),
 ]
 
 
@@ -127,6 +133,32 @@ def test_gemm_seeded(ops, K, d, M, parts, Kin, T, dtype, bias):
     assert_close_to_exact(bits_of(y), y32, dtype)
     ref0 = p.oracle_gemm(order=0, want_f32=False)
     assert_close_to_reference_order(bits_of(y), ref0, dtype)
+
+
+@pytest.mark.parametrize("K,d,M,parts,Kin,T,dtype,bias", [c for c in SEEDED if all(s % 16 == 0 for s in c[3])])
+def test_gemm_packed_equals_reference_layout(ops, K, d, M, parts, Kin, T, dtype, bias):
+    """pq_repack_codes + pq_gemm_packed give the bits pq_gemm gives on the reference layout (same sums
+    in the same order), and stay within the stated tolerance of the oracle."""
+    p = Problem(1234, K, d, M, parts, Kin, T, dtype, bias=bias).to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    name = ops.gemm_kernel_name(T, p.N, p.G, M, K, d, p.codes.element_size(), p.x.dtype, parts)
+    if K > 4096:                   # K = 65536: the codebook does not fit LDS, no MFMA kernel, no packed layout
+        assert packed is None and name == "generic"
+        return
+    assert packed is not None and packed.dtype == torch.uint8
+    pname = ops.gemm_kernel_name(T, p.N, p.G, M, K, d, p.codes.element_size(), p.x.dtype, parts, packed=True)
+    assert pname == ("mfma_tiled_packed" if T > 16 else "mfma_stream_packed")
+    y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(y), y32, dtype)
+    if name == "mfma_stream":
+        y_nat = ops.pq_gemm(p.x_dev, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+        assert_close_to_exact(bits_of(y_nat), y32, dtype)
+
+
+def test_repack_refuses_unaligned_partitions(ops):
+    p = Problem(2, 256, 8, 1, [40, 24], 128, 1, "bf16").to(DEV)
+    assert ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, [40, 24]) is None
 
 
 def test_gemm_input_shapes_and_strides(ops):

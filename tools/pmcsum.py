@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --pmc counter_collection CSV: per kernel (name, grid) the mean of each counter."""
+import collections
+import csv
+import glob
+import sys
+
+files = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in files:
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"]
+        name = name[name.find("pq::"):][:60] if "pq::" in name else name[:40]
+        key = (name, r.get("Grid_Size", r.get("Grid_Size_X", "")))
+        agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for key, ctrs in agg.items():
+    if "pq::" not in key[0]:
+        continue
+    print(key)
+    for c, v in sorted(ctrs.items()):
+        print(f"   {c:32s} n={len(v):4d} mean={sum(v)/len(v):16.1f}")

@@ -16,7 +16,7 @@ PQ_DTYPE_FP16, PQ_DTYPE_BF16 = 0, 1
 
 # every symbol include/pq_amd.h declares
 EXPORTS = ("pq_version", "pq_caps", "pq_last_error", "pq_dequant", "pq_gemm_workspace_bytes", "pq_gemm",
-           "pq_gemm_kernel_name")
+           "pq_packed_codes_bytes", "pq_repack_codes", "pq_gemm_packed", "pq_gemm_kernel_name")
 
 _lock = threading.Lock()
 _lib = None
@@ -60,7 +60,13 @@ def load():
         L.pq_gemm.argtypes = [vp, i32, i64, vp, vp, vp, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64,
                               vp, sz, vp]
         L.pq_gemm.restype = ctypes.c_int
-        L.pq_gemm_kernel_name.argtypes = [i32] * 8 + [pi32, i32, ctypes.c_char_p, sz]
+        L.pq_gemm_packed.argtypes = L.pq_gemm.argtypes
+        L.pq_gemm_packed.restype = ctypes.c_int
+        L.pq_packed_codes_bytes.argtypes = [pi32, i32, i32, i32, i32, i32, i32, i32]
+        L.pq_packed_codes_bytes.restype = sz
+        L.pq_repack_codes.argtypes = [vp, pi32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+        L.pq_repack_codes.restype = ctypes.c_int
+        L.pq_gemm_kernel_name.argtypes = [i32] * 8 + [pi32, i32, i32, ctypes.c_char_p, sz]
         L.pq_gemm_kernel_name.restype = ctypes.c_int
         if L.pq_version() != PQ_ABI_VERSION:
             raise PQLibraryError(f"{LIB_PATH}: ABI version {L.pq_version()} != {PQ_ABI_VERSION}")

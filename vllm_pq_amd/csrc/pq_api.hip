@@ -65,7 +65,7 @@ Kernel choose(const pq::GemmArgs &a) {
     }
     const bool st = pq::gemm_stream_supported(a);
     const bool ti = pq::gemm_tiled_supported(a);
-    if (ti && (a.T > 32 || !st)) return K_TILED;
+    if (ti && (a.T > 16 || !st)) return K_TILED;
     if (st) return K_STREAM;
     return K_GENERIC;
 }
@@ -115,7 +115,39 @@ static int fill_gemm(pq::GemmArgs &a, const char *fn, const void *x, int32_t T, 
         return fail(PQ_ERR_INVALID_ARGUMENT, "%s: y_row_stride=%lld < N=%d", fn, (long long)y_row_stride, N);
     a.x = x; a.T = T; a.x_stride = x_row_stride; a.codes = codes; a.codebooks = codebooks; a.scales = scales;
     a.bias = bias; a.N = N; a.G = G; a.M = M; a.K = K; a.d = d; a.code_bytes = code_bytes; a.dtype = dtype;
-    a.y = y; a.y_stride = y_row_stride; a.workspace = nullptr; a.workspace_bytes = 0;
+    a.y = y; a.y_stride = y_row_stride; a.workspace = nullptr; a.workspace_bytes = 0; a.packed = false;
+    return PQ_OK;
+}
+
+static int run_gemm(const char *fn, bool packed, const void *x, int32_t T, int64_t x_row_stride, const void *codes,
+                    const void *codebooks, const void *scales, const void *bias, const int32_t *part_sizes,
+                    int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes,
+                    int32_t dtype, void *y, int64_t y_row_stride, void *workspace, size_t workspace_bytes,
+                    void *stream) {
+    pq::GemmArgs a;
+    int rc = fill_gemm(a, fn, x, T, x_row_stride, codes, codebooks, scales, bias, part_sizes, num_parts, N, G, M, K,
+                       d, code_bytes, dtype, y, y_row_stride);
+    if (rc) return rc;
+    if (T == 0 || N == 0) return PQ_OK;
+    if (!y || !scales) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: NULL tensor pointer", fn);
+    if (G > 0 && (!x || !codes || !codebooks)) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: NULL tensor pointer", fn);
+    a.workspace = workspace;
+    a.workspace_bytes = workspace_bytes;
+    a.packed = packed;
+    if (packed && !pq::packable(a.parts, d, K, M, code_bytes))
+        return fail(PQ_ERR_UNSUPPORTED, "%s: this format has no packed layout (pq_packed_codes_bytes() == 0)", fn);
+    const Kernel k = choose(a);
+    if (packed && k == K_GENERIC)
+        return fail(PQ_ERR_INVALID_ARGUMENT,
+                    "%s: x, codebooks and packed_codes must be 16-byte aligned and x_row_stride a multiple of 8", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    switch (k) {
+    case K_TILED: e = pq::launch_gemm_tiled(a, s); break;
+    case K_STREAM: e = pq::launch_gemm_stream(a, s); break;
+    default: e = pq::launch_gemm_generic(a, s); break;
+    }
+    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "%s: %s", fn, hipGetErrorString(e));
     return PQ_OK;
 }
 
@@ -123,28 +155,46 @@ int pq_gemm(const void *x, int32_t T, int64_t x_row_stride, const void *codes, c
             const void *scales, const void *bias, const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G,
             int32_t M, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype, void *y, int64_t y_row_stride,
             void *workspace, size_t workspace_bytes, void *stream) {
-    pq::GemmArgs a;
-    int rc = fill_gemm(a, "pq_gemm", x, T, x_row_stride, codes, codebooks, scales, bias, part_sizes, num_parts, N, G,
-                       M, K, d, code_bytes, dtype, y, y_row_stride);
+    return run_gemm("pq_gemm", false, x, T, x_row_stride, codes, codebooks, scales, bias, part_sizes, num_parts, N, G,
+                    M, K, d, code_bytes, dtype, y, y_row_stride, workspace, workspace_bytes, stream);
+}
+
+int pq_gemm_packed(const void *x, int32_t T, int64_t x_row_stride, const void *packed_codes, const void *codebooks,
+                   const void *scales, const void *bias, const int32_t *part_sizes, int32_t num_parts, int32_t N,
+                   int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype, void *y,
+                   int64_t y_row_stride, void *workspace, size_t workspace_bytes, void *stream) {
+    return run_gemm("pq_gemm_packed", true, x, T, x_row_stride, packed_codes, codebooks, scales, bias, part_sizes,
+                    num_parts, N, G, M, K, d, code_bytes, dtype, y, y_row_stride, workspace, workspace_bytes, stream);
+}
+
+size_t pq_packed_codes_bytes(const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K,
+                             int32_t d, int32_t code_bytes) {
+    pq::Parts parts;
+    if (check_format("pq_packed_codes_bytes", part_sizes, num_parts, N, G, M, K, d, code_bytes, PQ_DTYPE_BF16, &parts))
+        return 0;
+    if (!pq::packable(parts, d, K, M, code_bytes)) return 0;
+    return pq::packed_bytes(N, G, M, code_bytes);
+}
+
+int pq_repack_codes(const void *codes, const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M,
+                    int32_t K, int32_t d, int32_t code_bytes, void *packed_codes, void *stream) {
+    pq::Parts parts;
+    int rc = check_format("pq_repack_codes", part_sizes, num_parts, N, G, M, K, d, code_bytes, PQ_DTYPE_BF16, &parts);
     if (rc) return rc;
-    if (T == 0 || N == 0) return PQ_OK;
-    if (!y || !scales) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_gemm: NULL tensor pointer");
-    if (G > 0 && (!x || !codes || !codebooks)) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_gemm: NULL tensor pointer");
-    a.workspace = workspace;
-    a.workspace_bytes = workspace_bytes;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e;
-    switch (choose(a)) {
-    case K_TILED: e = pq::launch_gemm_tiled(a, s); break;
-    case K_STREAM: e = pq::launch_gemm_stream(a, s); break;
-    default: e = pq::launch_gemm_generic(a, s); break;
-    }
-    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "pq_gemm: %s", hipGetErrorString(e));
+    if (!pq::packable(parts, d, K, M, code_bytes))
+        return fail(PQ_ERR_UNSUPPORTED, "pq_repack_codes: this format has no packed layout");
+    if (N == 0 || G == 0) return PQ_OK;
+    if (!codes || !packed_codes) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_repack_codes: NULL tensor pointer");
+    if (reinterpret_cast<uintptr_t>(packed_codes) & 15)
+        return fail(PQ_ERR_INVALID_ARGUMENT, "pq_repack_codes: packed_codes must be 16-byte aligned");
+    hipError_t e = pq::launch_repack(codes, N, G, M, d, code_bytes, packed_codes, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "pq_repack_codes: %s", hipGetErrorString(e));
     return PQ_OK;
 }
 
 int pq_gemm_kernel_name(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes,
-                        int32_t dtype, const int32_t *part_sizes, int32_t num_parts, char *buf, size_t buf_len) {
+                        int32_t dtype, const int32_t *part_sizes, int32_t num_parts, int32_t packed, char *buf,
+                        size_t buf_len) {
     pq::GemmArgs a;
     // aligned dummy pointers: the choice depends on alignment, which real tensors from an allocator have
     void *al = reinterpret_cast<void *>(uintptr_t(256));
@@ -152,8 +202,11 @@ int pq_gemm_kernel_name(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, i
                        G, M, K, d, code_bytes, dtype, al, N);
     if (rc) return rc;
     if (!buf || buf_len == 0) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_gemm_kernel_name: no buffer");
+    a.packed = packed != 0;
+    if (a.packed && !pq::packable(a.parts, d, K, M, code_bytes))
+        return fail(PQ_ERR_UNSUPPORTED, "pq_gemm_kernel_name: this format has no packed layout");
     static const char *names[] = {"generic", "mfma_stream", "mfma_tiled"};
-    snprintf(buf, buf_len, "%s", names[choose(a)]);
+    snprintf(buf, buf_len, "%s%s", names[choose(a)], a.packed ? "_packed" : "");
     return PQ_OK;
 }
 

@@ -1,0 +1,5 @@
+// bf16 instantiations of the streaming gather+MFMA kernel.
+#include "pq_gemm_stream_impl.cuh"
+namespace pq {
+hipError_t launch_gemm_stream_bf16(const GemmArgs &a, hipStream_t stream) { return launch_at<bf16_t>(a, stream); }
+}  // namespace pq

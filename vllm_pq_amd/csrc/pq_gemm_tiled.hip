@@ -1,10 +1,24 @@
-// Fused codebook gather + MFMA GEMM for large token counts (prefill) on gfx950.
+// Host side of the tiled gather+MFMA kernel (prefill): format checks and dtype dispatch.
 #include "pq_common.cuh"
 #include "pq_kernels.h"
 
 namespace pq {
 
-bool gemm_tiled_supported(const GemmArgs &) { return false; }
-hipError_t launch_gemm_tiled(const GemmArgs &, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_gemm_tiled_bf16(const GemmArgs &a, hipStream_t stream);
+hipError_t launch_gemm_tiled_fp16(const GemmArgs &a, hipStream_t stream);
+
+// Needs the PACKED code order, 16-byte aligned operands and a format the LDS image can hold.
+bool gemm_tiled_supported(const GemmArgs &a) {
+    if (!a.packed) return false;
+    if (!packable(a.parts, a.d, a.K, a.M, a.code_bytes)) return false;
+    if ((reinterpret_cast<uintptr_t>(a.x) & 15) || (a.x_stride % 8)) return false;
+    if ((reinterpret_cast<uintptr_t>(a.codes) & 15) || (reinterpret_cast<uintptr_t>(a.codebooks) & 15)) return false;
+    return true;
+}
+
+hipError_t launch_gemm_tiled(const GemmArgs &a, hipStream_t stream) {
+    if (a.N == 0 || a.T == 0) return hipSuccess;
+    return a.dtype == PQ_DTYPE_BF16 ? launch_gemm_tiled_bf16(a, stream) : launch_gemm_tiled_fp16(a, stream);
+}
 
 }  // namespace pq

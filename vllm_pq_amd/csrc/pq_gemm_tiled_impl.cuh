@@ -1,0 +1,309 @@
+// Fused codebook gather + MFMA GEMM for large token counts (prefill) on gfx950.
+//
+// y[t][n] = scale[n] * sum_k x[t][k] * W[n][k] + bias[n]
+//
+// A block of 8 waves owns a BN-row (n) x BT-token output tile and walks K in steps of 64.  The
+// weight is never staged: it is the MFMA A operand, and lane l's fragment (row l&15, k = 8(l>>4)..+7)
+// is one d=8 centroid (two d=4, four d=2), read with one ds_read_b128 from the replicated LDS
+// codebook image at the address the lane's code selects (see pq_gemm_stream_impl.cuh).  Only the
+// activations go through LDS: a [BT][64] tile per step, double buffered, XOR-swizzled so that the
+// B-operand reads (16 tokens x 4 k-octets per wave-instruction) are bank-conflict free.  A gathered
+// A fragment is reused for WT token fragments, an activation fragment for WN weight fragments.
+//
+// Codes come in the PACKED order (pq_gemm_stream.hip): per 16-row fragment and k-chunk one 16-byte
+// piece per lane holding the codes of that lane's KS k-steps, loaded once per chunk.
+//
+// Tile -> block map: blocks b and b+8 share an XCD (and its L2).  Each XCD takes a contiguous run of
+// (token tile, row tile) pairs in token-major order, so the blocks resident on one XCD read the same
+// activation tile from that XCD's L2 while each streams its own codes.
+#pragma once
+#include <stdlib.h>
+
+#include "pq_common.cuh"
+#include "pq_gather.cuh"
+#include "pq_kernels.h"
+#include "pq_stream_geom.cuh"
+
+namespace pq {
+
+constexpr int TL_THREADS = 512;
+constexpr int TL_WAVES = 8;
+constexpr int TL_BK = 64;    // k per LDS tile
+
+// byte offset of 16-byte slot `slot` (0..7) of row `row` inside a [rows][64] 16-bit tile
+__device__ inline uint32_t xt_off(int row, int slot) { return (uint32_t)row * 128u + (uint32_t)((slot ^ (row & 7)) << 4); }
+
+// WAVES_T of the 8 waves lie along the token axis, the rest along the row axis; a wave owns WN weight
+// fragments x WT token fragments, so the block tile is (8/WAVES_T * WN * 16) rows x (WAVES_T * WT * 16)
+// tokens.
+template <typename AT, typename CodeT, int D, int M, int WAVES_T, int WN, int WT>
+__global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
+    const uint16_t *__restrict__ x, int T, int64_t x_stride, const u32x4 *__restrict__ packed,
+    const uint16_t *__restrict__ codebooks, const uint16_t *__restrict__ scales, const uint16_t *__restrict__ bias,
+    Parts parts, int G, int K, int nbits, int R, uint16_t *__restrict__ y, int64_t y_stride, int n_tiles,
+    int t_tiles) {
+    typedef typename Act<AT>::vec8 vec8;
+    typedef StreamFmt<sizeof(CodeT), D, M> F;
+    constexpr int CB = sizeof(CodeT);
+    constexpr int EB = 2 * D;
+    constexpr int CG = F::CG, KS = F::KS, CPS = F::CPS;
+    constexpr int WAVES_N = TL_WAVES / WAVES_T;
+    constexpr int BN = WAVES_N * WN * 16;            // weight rows per block
+    constexpr int BT = WAVES_T * WT * 16;            // tokens per block
+    constexpr int XT_BYTES = BT * TL_BK * 2;         // one activation tile
+    constexpr int XLOADS = XT_BYTES / 16 / TL_THREADS;   // 16-byte pieces per thread per tile
+    // The codes of a chunk are consumed in PIECES register pieces (half a lane's 16 bytes when the chunk
+    // has >= 4 k-steps), so that the next piece can be prefetched without doubling the live registers.
+    constexpr int SPP = KS >= 4 ? KS / 2 : KS;       // k-steps per code piece
+    constexpr int PIECES = KS / SPP;                 // pieces per chunk: 1 or 2
+    constexpr int PW = 4 / PIECES;                   // dwords per piece
+    constexpr int TPP = SPP / 2;                     // 64-k tiles per piece
+    typedef uint32_t piece_t __attribute__((ext_vector_type(PW)));
+    static_assert(KS % 2 == 0, "a code chunk must cover whole 64-k tiles");
+    static_assert(XLOADS >= 1, "tile too small for the block");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *xt = smem + ST_MAX_LDS_CB;        // two activation tiles behind the codebook image
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+    const int wn = wave / WAVES_T;                   // wave's position along n
+    const int wt = wave % WAVES_T;                   // and along t
+
+    // ---- XCD-aware tile assignment --------------------------------------------------------------
+    const int total = n_tiles * t_tiles;
+    const int per_xcd = (total + 7) >> 3;
+    const int pair = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (pair >= total) return;
+    const int t_tile = pair / n_tiles;
+    const TileLoc loc = locate_tile(parts, pair - t_tile * n_tiles, BN);
+    const int t0 = t_tile * BT;
+    const int row_end = loc.row0 + loc.nrows;
+    const int Kin = G * D;
+    const int nchunks = (G + CG - 1) / CG;
+    const int nfr = (loc.nrows + 15) >> 4;           // valid fragments in this row tile
+    const int f0 = loc.row0 >> 4;
+
+    // ---- codebook image (entries first: they are needed before the first gather) -----------------
+    {
+        CodebookImage<D, TL_THREADS> img;
+        img.load(reinterpret_cast<const unsigned char *>(codebooks) + (size_t)loc.part * M * K * EB, M * K, R, tid);
+        img.store(smem, M * K, R, tid);
+    }
+
+    // ---- activation tile staging: thread -> XLOADS 16-byte pieces, 8 pieces per 128-byte row ------
+    // Loads are unconditional (clamped addresses) and nothing touches the loaded registers until
+    // x_store, so the loads stay in flight across the tile's MFMAs.  Tokens past T read the last valid
+    // row: their outputs are never stored.  Only k past Kin (a ragged last tile) must read as zero.
+    u32x4 xs[XLOADS];
+    const bool ragged_k = (Kin % TL_BK) != 0;
+    auto x_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < XLOADS; ++i) {
+            const int piece = tid + i * TL_THREADS;
+            const int row = piece >> 3, slot = piece & 7;
+            const int t = t0 + row, k = kt * TL_BK + slot * 8;
+            xs[i] = *reinterpret_cast<const u32x4 *>(x + (size_t)(t < T ? t : T - 1) * x_stride + (k < Kin ? k : 0));
+        }
+    };
+    auto x_store = [&](int buf, int kt) {
+#pragma unroll
+        for (int i = 0; i < XLOADS; ++i) {
+            const int piece = tid + i * TL_THREADS;
+            u32x4 v = xs[i];
+            if (ragged_k && kt * TL_BK + (piece & 7) * 8 >= Kin) v = u32x4{0, 0, 0, 0};
+            *reinterpret_cast<u32x4 *>(xt + buf * XT_BYTES + xt_off(piece >> 3, piece & 7)) = v;
+        }
+    };
+
+    f32x4 acc[WN][WT];
+#pragma unroll
+    for (int i = 0; i < WN; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t shift = (uint32_t)__builtin_ctz((unsigned)(EB * R));
+    const uint32_t lane_off = (uint32_t)(lane & (R - 1)) * EB;
+    const uint32_t cb_stride = (uint32_t)K * EB * R;
+    const int ntiles_k = (Kin + TL_BK - 1) / TL_BK;
+
+    x_load(0);
+    x_store(0, 0);
+    __syncthreads();
+
+    const unsigned char *pk_bytes = reinterpret_cast<const unsigned char *>(packed);
+    auto load_piece = [&](piece_t (&dst)[WN], int p) {
+        const int c = p / PIECES, half = p % PIECES;
+#pragma unroll
+        for (int i = 0; i < WN; ++i) {
+            const int fi = wn * WN + i;
+            const int f = f0 + (fi < nfr ? fi : nfr - 1);
+            dst[i] = *reinterpret_cast<const piece_t *>(pk_bytes + (((size_t)f * nchunks + c) * 64 + lane) * 16 +
+                                                        half * (16 / PIECES));
+        }
+    };
+    const int npieces = nchunks * PIECES;
+    piece_t cw[WN], cwn[WN];
+    load_piece(cw, 0);
+    for (int p = 0; p < npieces; ++p) {
+        if (p + 1 < npieces) load_piece(cwn, p + 1);   // in flight during this piece's TPP tiles
+#pragma unroll
+        for (int it = 0; it < TPP; ++it) {
+            const int kt = p * TPP + it;
+            if (kt >= ntiles_k) break;
+            const int buf = kt & 1;
+            const bool more = kt + 1 < ntiles_k;
+            if (more) x_load(kt + 1);
+            const unsigned char *xb = xt + buf * XT_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int s = it * 2 + ks;             // k-step within the piece (compile-time)
+                vec8 xf[WT];
+#pragma unroll
+                for (int j = 0; j < WT; ++j) {
+                    const int row = (wt * WT + j) * 16 + r16;
+                    xf[j] = *reinterpret_cast<const vec8 *>(xb + xt_off(row, ks * 4 + q));
+                }
+#pragma unroll
+                for (int i = 0; i < WN; ++i) {
+                    vec8 a;
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        uint32_t idx[CPS];
+#pragma unroll
+                        for (int u = 0; u < CPS; ++u)
+                            idx[u] = code_at<CB>(cw[i], (s * CPS + u) * M + m, (uint32_t)nbits);
+                        const vec8 am = gather_frag<AT, D>(smem + m * cb_stride, idx, shift, lane_off);
+                        a = m == 0 ? am : Act<AT>::add8(a, am);
+                    }
+#pragma unroll
+                    for (int j = 0; j < WT; ++j) acc[i][j] = Act<AT>::mfma16(a, xf[j], acc[i][j]);
+                }
+            }
+            if (more) x_store(buf ^ 1, kt + 1);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < WN; ++i) cw[i] = cwn[i];
+    }
+
+    // ---- epilogue: scale, bias, round, store (lane holds 4 consecutive rows of one token) --------
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+        const int nb = loc.row0 + (wn * WN + i) * 16 + q * 4;
+        if (nb >= row_end) continue;
+        float sc[4], bi[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nb + r < row_end ? nb + r : row_end - 1;
+            sc[r] = Act<AT>::to_f32(scales[n]);
+            bi[r] = bias ? Act<AT>::to_f32(bias[n]) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+            const int t = t0 + (wt * WT + j) * 16 + r16;
+            if (t >= T) continue;
+            uint16_t h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = Act<AT>::from_f32(acc[i][j][r] * sc[r] + bi[r]);
+            uint16_t *yp = y + (size_t)t * y_stride + nb;
+            if (nb + 4 <= row_end && (reinterpret_cast<uintptr_t>(yp) & 7) == 0) {
+                u32x2 o2;
+                o2.x = h[0] | ((uint32_t)h[1] << 16);
+                o2.y = h[2] | ((uint32_t)h[3] << 16);
+                *reinterpret_cast<u32x2 *>(yp) = o2;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nb + r < row_end) yp[r] = h[r];
+            }
+        }
+    }
+}
+
+// ---- per-dtype launcher ---------------------------------------------------------------------------
+template <typename AT, typename CodeT, int D, int M, int WAVES_T, int WN, int WT>
+static hipError_t tiled_launch_cfg(const GemmArgs &a, hipStream_t stream) {
+    constexpr int BN = (TL_WAVES / WAVES_T) * WN * 16;
+    constexpr int BT = WAVES_T * WT * 16;
+    const int R = stream_replication<D>(a.K, a.M);
+    const int nbits = __builtin_ctz((unsigned)a.K);
+    const int n_tiles = tiles_in(a.parts, BN);
+    const int t_tiles = (a.T + BT - 1) / BT;
+    const int total = n_tiles * t_tiles;
+    const int per_xcd = (total + 7) / 8;
+    const size_t lds = (size_t)ST_MAX_LDS_CB + 2 * (size_t)BT * TL_BK * 2;
+    auto kern = gemm_tiled_kernel<AT, CodeT, D, M, WAVES_T, WN, WT>;
+    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(TL_THREADS), lds, stream, static_cast<const uint16_t *>(a.x), a.T,
+                       a.x_stride, static_cast<const u32x4 *>(a.codes), static_cast<const uint16_t *>(a.codebooks),
+                       static_cast<const uint16_t *>(a.scales), static_cast<const uint16_t *>(a.bias), a.parts, a.G,
+                       a.K, nbits, R, static_cast<uint16_t *>(a.y), a.y_stride, n_tiles, t_tiles);
+    return hipGetLastError();
+}
+
+// Tile shapes, largest first: {rows, tokens}.  Bigger tiles reuse each gathered weight fragment and
+// each activation fragment more often; smaller ones give the 256 CUs enough blocks.
+struct TiledCfg { int bn, bt; };
+static const TiledCfg kTiledCfgs[] = {{256, 256}, {256, 128}, {128, 128}, {256, 64}, {128, 64}, {64, 64}};
+constexpr int kNumTiledCfgs = 6;
+
+static int choose_tiled_cfg(const GemmArgs &a) {
+    const char *env = getenv("PQ_AMD_TILED_CFG");
+    if (env && *env) {
+        const int v = atoi(env);
+        if (v >= 0 && v < kNumTiledCfgs) return v;
+    }
+    // Token tile: do not pad T by more than it has to be; then the largest row tile that still yields
+    // about one block per CU, else the shape with the most blocks.
+    int best = kNumTiledCfgs - 1;
+    long best_blocks = -1;
+    for (int i = 0; i < kNumTiledCfgs; ++i) {
+        const TiledCfg &c = kTiledCfgs[i];
+        if (c.bt > 64 && a.T <= c.bt / 2) continue;                 // more than half the tile would be padding
+        const long blocks = (long)tiles_in(a.parts, c.bn) * ((a.T + c.bt - 1) / c.bt);
+        if (blocks >= 200) return i;
+        if (blocks > best_blocks) { best_blocks = blocks; best = i; }
+    }
+    return best;
+}
+
+template <typename AT, typename CodeT, int D, int M>
+static hipError_t tiled_launch_fmt(const GemmArgs &a, hipStream_t stream) {
+    switch (choose_tiled_cfg(a)) {
+    case 0: return tiled_launch_cfg<AT, CodeT, D, M, 4, 8, 4>(a, stream);   // 256 x 256
+    case 1: return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4>(a, stream);   // 256 x 128
+    case 2: return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 4>(a, stream);   // 128 x 128
+    case 3: return tiled_launch_cfg<AT, CodeT, D, M, 1, 2, 4>(a, stream);   // 256 x 64
+    case 4: return tiled_launch_cfg<AT, CodeT, D, M, 1, 1, 4>(a, stream);   // 128 x 64
+    default: return tiled_launch_cfg<AT, CodeT, D, M, 2, 1, 2>(a, stream);  //  64 x 64
+    }
+}
+
+template <typename AT>
+static hipError_t tiled_launch_at(const GemmArgs &a, hipStream_t stream) {
+    if (a.M == 2) return tiled_launch_fmt<AT, int8_t, 8, 2>(a, stream);
+    if (a.code_bytes == 1) {
+        switch (a.d) {
+        case 8: return tiled_launch_fmt<AT, int8_t, 8, 1>(a, stream);
+        case 4: return tiled_launch_fmt<AT, int8_t, 4, 1>(a, stream);
+        default: return tiled_launch_fmt<AT, int8_t, 2, 1>(a, stream);
+        }
+    }
+    switch (a.d) {
+    case 8: return tiled_launch_fmt<AT, int16_t, 8, 1>(a, stream);
+    case 4: return tiled_launch_fmt<AT, int16_t, 4, 1>(a, stream);
+    default: return tiled_launch_fmt<AT, int16_t, 2, 1>(a, stream);
+    }
+}
+
+}  // namespace pq

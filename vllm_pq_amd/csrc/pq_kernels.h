@@ -31,6 +31,7 @@ struct GemmArgs {
     int64_t y_stride;
     void *workspace;
     size_t workspace_bytes;
+    bool packed;  // codes are in the kernel-native PACKED order (pq_gemm_stream.hip)
 };
 
 hipError_t launch_dequant(const DequantArgs &a, hipStream_t stream);
@@ -41,6 +42,13 @@ hipError_t launch_gemm_generic(const GemmArgs &a, hipStream_t stream);
 // Fused gather + MFMA, weight-streaming (small T).  supported() says whether the format fits.
 bool gemm_stream_supported(const GemmArgs &a);
 hipError_t launch_gemm_stream(const GemmArgs &a, hipStream_t stream);
+
+// Load-time re-layout of the codes for the MFMA kernels.
+bool stream_format_supported(int d, int K, int M, int code_bytes);
+bool packable(const Parts &parts, int d, int K, int M, int code_bytes);
+size_t packed_bytes(int N, int G, int M, int code_bytes);
+hipError_t launch_repack(const void *codes, int N, int G, int M, int d, int code_bytes, void *packed,
+                         hipStream_t stream);
 
 // Fused gather + MFMA, LDS-tiled activations (large T).
 bool gemm_tiled_supported(const GemmArgs &a);

@@ -88,9 +88,10 @@ def _pq_dequant_impl(codes: torch.Tensor, codebooks: torch.Tensor, codebook_part
 
 
 def _pq_gemm_impl(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor,
-                  codebook_partition_sizes: List[int], bias: Optional[torch.Tensor]) -> torch.Tensor:
+                  codebook_partition_sizes: List[int], bias: Optional[torch.Tensor],
+                  packed_codes: Optional[torch.Tensor] = None) -> torch.Tensor:
     L = _lib.load()
-    dev = _check_device(input, codes, codebooks, scales, bias)
+    dev = _check_device(input, codes, codebooks, scales, bias, packed_codes)
     N, G, M, K, d, parts = _format(codes, codebooks, codebook_partition_sizes)
     if input.dtype != codebooks.dtype:
         raise ValueError(f"input dtype {input.dtype} != codebooks dtype {codebooks.dtype}")
@@ -101,10 +102,11 @@ def _pq_gemm_impl(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Ten
     if bias is not None and (bias.numel() != N or bias.dtype != input.dtype):
         raise ValueError("bias must hold one value of the activation dtype per output row")
     x2 = input.reshape(-1, input.shape[-1])
-    if x2.stride(-1) != 1:
+    if x2.stride(-1) != 1 or (packed_codes is not None and (x2.data_ptr() % 16 or x2.stride(0) % 8)):
         x2 = x2.contiguous()
     T = x2.shape[0]
-    codes = codes.contiguous()
+    if packed_codes is None:
+        codes = codes.contiguous()
     codebooks = codebooks.contiguous()
     scales = scales.contiguous()
     if bias is not None:
@@ -112,7 +114,9 @@ def _pq_gemm_impl(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Ten
     out = torch.empty((T, N), dtype=input.dtype, device=dev)
     if T and N:
         with torch.cuda.device(dev):
-            rc = L.pq_gemm(x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, codes.data_ptr(),
+            fn = L.pq_gemm if packed_codes is None else L.pq_gemm_packed
+            cptr = codes.data_ptr() if packed_codes is None else packed_codes.data_ptr()
+            rc = fn(x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, cptr,
                            codebooks.data_ptr(), scales.data_ptr(), bias.data_ptr() if bias is not None else None,
                            _lib.parts_array(parts), len(parts), N, G, M, K, d, _CODE_BYTES[codes.dtype],
                            _DTYPE[input.dtype], out.data_ptr(), N, None, 0, _stream_ptr(dev))
@@ -135,6 +139,16 @@ if _HAVE_CUSTOM_OP:
     def _gemm_fake(input, codes, codebooks, scales, codebook_partition_sizes, bias):
         return input.new_empty(input.shape[:-1] + (codes.shape[0],))
 
+    @torch.library.custom_op("pq_amd::gemm_packed", mutates_args=(), device_types="cuda")
+    def _gemm_packed_op(input: torch.Tensor, packed_codes: torch.Tensor, codes: torch.Tensor,
+                        codebooks: torch.Tensor, scales: torch.Tensor, codebook_partition_sizes: List[int],
+                        bias: Optional[torch.Tensor]) -> torch.Tensor:
+        return _pq_gemm_impl(input, codes, codebooks, scales, codebook_partition_sizes, bias, packed_codes)
+
+    @_gemm_packed_op.register_fake
+    def _gemm_packed_fake(input, packed_codes, codes, codebooks, scales, codebook_partition_sizes, bias):
+        return input.new_empty(input.shape[:-1] + (codes.shape[0],))
+
     @torch.library.custom_op("pq_amd::dequant", mutates_args=(), device_types="cuda")
     def _dequant_op(codes: torch.Tensor, codebooks: torch.Tensor, codebook_partition_sizes: List[int],
                     scales: Optional[torch.Tensor]) -> torch.Tensor:
@@ -154,6 +168,39 @@ def pq_gemm(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor, s
     return _pq_gemm_impl(input, codes, codebooks, scales, codebook_partition_sizes, bias)
 
 
+def pq_gemm_packed(input: torch.Tensor, packed_codes: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor,
+                   scales: torch.Tensor, codebook_partition_sizes: List[int],
+                   bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """pq_gemm reading the codes from `packed_codes` (pq_repack_codes); `codes` only supplies the
+    shape and dtype of the reference-layout tensor.  Same results as pq_gemm bit for bit."""
+    if _HAVE_CUSTOM_OP and input.is_cuda:
+        return torch.ops.pq_amd.gemm_packed(input, packed_codes, codes, codebooks, scales,
+                                            list(codebook_partition_sizes), bias)
+    return _pq_gemm_impl(input, codes, codebooks, scales, codebook_partition_sizes, bias, packed_codes)
+
+
+def pq_repack_codes(codes: torch.Tensor, codebooks: torch.Tensor,
+                    codebook_partition_sizes: List[int]) -> Optional[torch.Tensor]:
+    """Load-time re-layout of `codes` into the order the MFMA kernels stream (one contiguous KiB per
+    16-row fragment and k-chunk).  Returns a uint8 tensor, or None when the format has no packed
+    layout (the caller keeps using pq_gemm on the reference layout)."""
+    L = _lib.load()
+    dev = _check_device(codes, codebooks)
+    N, G, M, K, d, parts = _format(codes, codebooks, codebook_partition_sizes)
+    pa = _lib.parts_array(parts)
+    nbytes = L.pq_packed_codes_bytes(pa, len(parts), N, G, M, K, d, _CODE_BYTES[codes.dtype])
+    if nbytes == 0:
+        return None
+    codes = codes.contiguous()
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.pq_repack_codes(codes.data_ptr(), pa, len(parts), N, G, M, K, d, _CODE_BYTES[codes.dtype],
+                               packed.data_ptr(), _stream_ptr(dev))
+    if rc:
+        _raise(rc)
+    return packed
+
+
 def pq_dequant(codes: torch.Tensor, codebooks: torch.Tensor, codebook_partition_sizes: List[int],
                scales: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Dense [out_features, in_features] weight.  With scales=None: same signature and result as
@@ -165,14 +212,14 @@ def pq_dequant(codes: torch.Tensor, codebooks: torch.Tensor, codebook_partition_
 
 
 def gemm_kernel_name(T: int, N: int, G: int, M: int, K: int, d: int, code_bytes: int, dtype: torch.dtype,
-                     partition_sizes) -> str:
+                     partition_sizes, packed: bool = False) -> str:
     """Name of the kernel pq_gemm selects for a problem (no GPU needed)."""
     import ctypes
     L = _lib.load()
     buf = ctypes.create_string_buffer(64)
     parts = [int(s) for s in partition_sizes] if len(partition_sizes) else [N]
-    rc = L.pq_gemm_kernel_name(T, N, G, M, K, d, code_bytes, _DTYPE[dtype], _lib.parts_array(parts), len(parts), buf,
-                               64)
+    rc = L.pq_gemm_kernel_name(T, N, G, M, K, d, code_bytes, _DTYPE[dtype], _lib.parts_array(parts), len(parts),
+                               int(packed), buf, 64)
     if rc:
         _raise(rc)
     return buf.value.decode()

@@ -143,17 +143,26 @@ class PQLinearMethod(LinearMethodBase):
             set_weight_attrs(p, extra_weight_attrs)
 
     def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
-        # The kernels read the reference layout directly; only make sure the tensors are dense.
         # Integer codes left uninitialised by a dummy load are valid indices as they are
         # (index = value mod K).
         for name in ("codes", "codebooks", "scales"):
             p = getattr(layer, name)
             if not p.data.is_contiguous():
                 p.data = p.data.contiguous()
+        # Re-lay the codes out in the order the MFMA kernels stream them (kept beside the reference
+        # layout, which the checkpoint loaders and pq_dequant use).  On a CPU-resident layer (weights
+        # not moved to the GPU yet) there is nothing to do: apply() needs the GPU anyway.
+        layer.pq_packed_codes = None
+        if layer.codes.is_cuda:
+            parts = getattr(layer.codebooks, "output_partition_sizes", [])
+            layer.pq_packed_codes = ops.pq_repack_codes(layer.codes.data, layer.codebooks.data, parts)
 
     def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         codebooks = layer.codebooks
         parts = getattr(codebooks, "output_partition_sizes", [])
+        packed = getattr(layer, "pq_packed_codes", None)
+        if packed is not None:
+            return ops.pq_gemm_packed(x, packed, layer.codes, codebooks, layer.scales, parts, bias)
         return ops.pq_gemm(x, layer.codes, codebooks, layer.scales, parts, bias)
 
 
