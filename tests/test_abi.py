@@ -1,0 +1,99 @@
+"""The C ABI library loads without a GPU, exports every symbol include/pq_amd.h declares, and rejects
+bad arguments before touching the device.  CPU only (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from vllm_pq_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "pq_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pq_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_functions()
+    assert "pq_gemm" in names and "pq_dequant" in names and "pq_repack_codes" in names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/pq_amd.h but not exported"
+    assert sorted(_lib.EXPORTS) == names, "vllm_pq_amd/_lib.py EXPORTS out of sync with the header"
+
+
+def test_version_and_caps():
+    L = _lib.load()
+    assert L.pq_version() == 1
+    caps = L.pq_caps()
+    assert caps & 1 and caps & 2 and caps & (1 << 4) and caps & (1 << 5)
+
+
+def _gemm_rc(L, **kw):
+    a = dict(x=256, T=4, xs=128, codes=256, cb=256, sc=256, bias=None, parts=[64], N=64, G=16, M=1, K=256, d=8,
+             code_bytes=1, dtype=1, y=256, ys=64)
+    a.update(kw)
+    pa = _lib.parts_array(a["parts"]) if a["parts"] is not None else None
+    return L.pq_gemm(a["x"], a["T"], a["xs"], a["codes"], a["cb"], a["sc"], a["bias"], pa,
+                     len(a["parts"]) if a["parts"] is not None else 1, a["N"], a["G"], a["M"], a["K"], a["d"],
+                     a["code_bytes"], a["dtype"], a["y"], a["ys"], None, 0, None)
+
+
+def test_argument_validation_needs_no_gpu():
+    L = _lib.load()
+    # sum(part_sizes) != N  (aqlm.py:112)
+    assert _gemm_rc(L, parts=[32, 16]) == 1 and "sum(part_sizes)" in _lib.last_error()
+    # K not a power of two (aqlm.py:86)
+    assert _gemm_rc(L, K=200) == 1 and "power of two" in _lib.last_error()
+    # K too large for int8 codes (get_int_dtype, aqlm.py:20-29)
+    assert _gemm_rc(L, K=4096) == 1
+    assert _gemm_rc(L, code_bytes=4) == 2            # int32 codes: unsupported
+    assert _gemm_rc(L, dtype=7) == 1
+    assert _gemm_rc(L, xs=64) == 1                   # row stride shorter than in_features
+    assert _gemm_rc(L, ys=8) == 1
+    assert _gemm_rc(L, parts=[8] * 9, N=72) == 1     # more than PQ_MAX_PARTS partitions
+    assert _gemm_rc(L, x=None) == 1 and "NULL" in _lib.last_error()
+    # empty problems are fine and launch nothing
+    assert _gemm_rc(L, T=0) == 0
+    assert _gemm_rc(L, N=0, parts=[0], ys=0) == 0
+
+
+def test_packed_size_and_kernel_choice():
+    L = _lib.load()
+    pa = _lib.parts_array([4096, 1024, 1024])
+    # one KiB per 16-row fragment and 64-group chunk
+    assert L.pq_packed_codes_bytes(pa, 3, 6144, 512, 1, 256, 8, 1) == (6144 // 16) * 8 * 1024
+    assert L.pq_packed_codes_bytes(_lib.parts_array([40, 24]), 2, 64, 16, 1, 256, 8, 1) == 0    # partitions % 16
+    assert L.pq_packed_codes_bytes(_lib.parts_array([64]), 1, 64, 64, 1, 65536, 8, 2) == 0      # K too large for LDS
+    from vllm_pq_amd import ops
+    name = ops.gemm_kernel_name
+    assert name(1, 6144, 512, 1, 256, 8, 1, torch.bfloat16, [4096, 1024, 1024], packed=True) == "mfma_stream_packed"
+    assert name(4096, 6144, 512, 1, 256, 8, 1, torch.bfloat16, [4096, 1024, 1024], packed=True) == "mfma_tiled_packed"
+    assert name(4, 64, 64, 1, 65536, 8, 2, torch.float16, [64]) == "generic"
+    assert name(4, 60, 17, 1, 256, 8, 1, torch.float16, [60]) == "generic"
+    with pytest.raises(ValueError):
+        name(4, 64, 16, 1, 256, 8, 1, torch.bfloat16, [40, 24], packed=True)
+
+
+def test_ops_raise_on_cpu_tensors():
+    from vllm_pq_amd import ops
+    codes = torch.zeros(64, 16, 1, dtype=torch.int8)
+    cb = torch.zeros(1, 256, 1, 8, dtype=torch.bfloat16)
+    sc = torch.ones(64, 1, 1, 1, dtype=torch.bfloat16)
+    x = torch.zeros(2, 128, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.pq_gemm(x, codes, cb, sc, [64], None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.pq_dequant(codes, cb, [64])
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.PQLibraryError, match="no fallback"):
+        _lib.load()

@@ -52,10 +52,10 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     constexpr int BT = WAVES_T * WT * 16;            // tokens per block
     constexpr int XT_BYTES = BT * TL_BK * 2;         // one activation tile
     constexpr int XLOADS = XT_BYTES / 16 / TL_THREADS;   // 16-byte pieces per thread per tile
-    // The codes of a chunk are consumed in PIECES register pieces (half a lane's 16 bytes when the chunk
-    // has >= 4 k-steps), so that the next piece can be prefetched without doubling the live registers.
-    constexpr int SPP = KS >= 4 ? KS / 2 : KS;       // k-steps per code piece
-    constexpr int PIECES = KS / SPP;                 // pieces per chunk: 1 or 2
+    // The codes of a chunk are consumed in PIECES register pieces (a half or a quarter of a lane's 16
+    // bytes), so that the next piece can be prefetched with few live registers.
+    constexpr int SPP = KS >= 8 ? KS / 4 : KS >= 4 ? KS / 2 : KS;   // k-steps per code piece
+    constexpr int PIECES = KS / SPP;                 // pieces per chunk: 1, 2 or 4
     constexpr int PW = 4 / PIECES;                   // dwords per piece
     constexpr int TPP = SPP / 2;                     // 64-k tiles per piece
     typedef uint32_t piece_t __attribute__((ext_vector_type(PW)));
@@ -97,24 +97,33 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     // ---- activation tile staging: thread -> XLOADS 16-byte pieces, 8 pieces per 128-byte row ------
     // Loads are unconditional (clamped addresses) and nothing touches the loaded registers until
     // x_store, so the loads stay in flight across the tile's MFMAs.  Tokens past T read the last valid
-    // row: their outputs are never stored.  Only k past Kin (a ragged last tile) must read as zero.
+    // row: their outputs are never stored.
     u32x4 xs[XLOADS];
-    const bool ragged_k = (Kin % TL_BK) != 0;
-    auto x_load = [&](int kt) {
+    const int npieces = nchunks * PIECES;
+    const int ntiles_k = npieces * TPP;              // tiles walked (whole code pieces)
+    const int nvalid_k = Kin / TL_BK;                // Kin % 64 == 0 (checked on the host); tiles past it are zero
+    // byte offsets of this thread's pieces from the tile's first token row (block-local, fits 32 bits)
+    const unsigned char *xbase = reinterpret_cast<const unsigned char *>(x + (size_t)t0 * x_stride);
+    uint32_t xoff[XLOADS];
 #pragma unroll
-        for (int i = 0; i < XLOADS; ++i) {
-            const int piece = tid + i * TL_THREADS;
-            const int row = piece >> 3, slot = piece & 7;
-            const int t = t0 + row, k = kt * TL_BK + slot * 8;
-            xs[i] = *reinterpret_cast<const u32x4 *>(x + (size_t)(t < T ? t : T - 1) * x_stride + (k < Kin ? k : 0));
-        }
+    for (int i = 0; i < XLOADS; ++i) {
+        const int piece = tid + i * TL_THREADS;
+        int row = piece >> 3;
+        row = t0 + row < T ? row : T - 1 - t0;
+        xoff[i] = (uint32_t)row * (uint32_t)(x_stride * 2) + (uint32_t)(piece & 7) * 16u;
+    }
+    auto x_load = [&](int kt) {
+        // tiles past Kin (padding of the last code piece) re-read the last valid tile; x_store zeroes them
+        const uint32_t kb = (uint32_t)(kt < nvalid_k ? kt : nvalid_k - 1) * (TL_BK * 2);
+#pragma unroll
+        for (int i = 0; i < XLOADS; ++i) xs[i] = *reinterpret_cast<const u32x4 *>(xbase + (xoff[i] + kb));
     };
     auto x_store = [&](int buf, int kt) {
 #pragma unroll
         for (int i = 0; i < XLOADS; ++i) {
             const int piece = tid + i * TL_THREADS;
             u32x4 v = xs[i];
-            if (ragged_k && kt * TL_BK + (piece & 7) * 8 >= Kin) v = u32x4{0, 0, 0, 0};
+            if (kt >= nvalid_k) v = u32x4{0, 0, 0, 0};
             *reinterpret_cast<u32x4 *>(xt + buf * XT_BYTES + xt_off(piece >> 3, piece & 7)) = v;
         }
     };
@@ -128,35 +137,35 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     const uint32_t shift = (uint32_t)__builtin_ctz((unsigned)(EB * R));
     const uint32_t lane_off = (uint32_t)(lane & (R - 1)) * EB;
     const uint32_t cb_stride = (uint32_t)K * EB * R;
-    const int ntiles_k = (Kin + TL_BK - 1) / TL_BK;
 
     x_load(0);
     x_store(0, 0);
     __syncthreads();
 
-    const unsigned char *pk_bytes = reinterpret_cast<const unsigned char *>(packed);
-    auto load_piece = [&](piece_t (&dst)[WN], int p) {
-        const int c = p / PIECES, half = p % PIECES;
+    // fragment bases are wave-uniform (scalar registers); the per-lane part is one 32-bit offset
+    const unsigned char *fbase[WN];
 #pragma unroll
-        for (int i = 0; i < WN; ++i) {
-            const int fi = wn * WN + i;
-            const int f = f0 + (fi < nfr ? fi : nfr - 1);
-            dst[i] = *reinterpret_cast<const piece_t *>(pk_bytes + (((size_t)f * nchunks + c) * 64 + lane) * 16 +
-                                                        half * (16 / PIECES));
-        }
+    for (int i = 0; i < WN; ++i) {
+        const int fi = wn * WN + i;
+        const int f = f0 + (fi < nfr ? fi : nfr - 1);
+        fbase[i] = reinterpret_cast<const unsigned char *>(packed) + (size_t)f * nchunks * 1024;
+    }
+    auto load_piece = [&](piece_t (&dst)[WN], int p) {
+        const uint32_t off = (uint32_t)(p / PIECES) * 1024u + (uint32_t)lane * 16u + (uint32_t)(p % PIECES) * (16u / PIECES);
+#pragma unroll
+        for (int i = 0; i < WN; ++i) dst[i] = *reinterpret_cast<const piece_t *>(fbase[i] + off);
     };
-    const int npieces = nchunks * PIECES;
+    // No branch around any load in the loop: a conditional load makes hipcc drain vmcnt at the join, which
+    // would expose the whole global-load latency in every tile.  The last piece / tile re-loads itself.
     piece_t cw[WN], cwn[WN];
     load_piece(cw, 0);
     for (int p = 0; p < npieces; ++p) {
-        if (p + 1 < npieces) load_piece(cwn, p + 1);   // in flight during this piece's TPP tiles
+        load_piece(cwn, p + 1 < npieces ? p + 1 : p);  // in flight during this piece's TPP tiles
 #pragma unroll
         for (int it = 0; it < TPP; ++it) {
             const int kt = p * TPP + it;
-            if (kt >= ntiles_k) break;
             const int buf = kt & 1;
-            const bool more = kt + 1 < ntiles_k;
-            if (more) x_load(kt + 1);
+            x_load(kt + 1 < ntiles_k ? kt + 1 : kt);
             const unsigned char *xb = xt + buf * XT_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
                     for (int j = 0; j < WT; ++j) acc[i][j] = Act<AT>::mfma16(a, xf[j], acc[i][j]);
                 }
             }
-            if (more) x_store(buf ^ 1, kt + 1);
+            x_store(buf ^ 1, kt + 1);                   // after the last tile nobody reads it
             __syncthreads();
         }
 #pragma unroll
