@@ -206,6 +206,21 @@ def cpu_baseline(T, dtype, budget_s=12.0, cap_s=30.0):
                       f"generic_dequantize_gemm"}
 
 
+def profiled_traffic(key):
+    """HBM bytes per launch of a kernel as measured by the committed rocprofv3 counter passes
+    (profiles/traffic_r*.json, newest round first); None when that launch was not profiled."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f).get(key)
+            if rec:
+                return rec["hbm_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
+    return None
+
+
 def measure(stack, T, steps, warmup, device, dtype, world, dist_on, use_graph):
     inputs = make_inputs(stack[0], T, device, dtype)
     runner = StepRunner(stack, inputs, use_graph)
@@ -279,7 +294,7 @@ def main():
     else:
         roof = {"bound": "hbm", "achieved": k_bytes / t_k / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["traffic"] = None
+    roof["traffic"] = profiled_traffic(f"{dom}@T{T}:{kname}") if world == 1 else None
     roof.update({"kernel": f"{kname}:{dom}", "launch_us": t_k * 1e6, "launches_timed": reps,
                  "algorithmic_bytes": k_bytes, "algorithmic_flops": k_flops})
 
@@ -292,7 +307,10 @@ def main():
         decode = {"tokens": Td, "ms_per_step": dm["per_step"] * 1e3, "tflops": dm["tflops"], "hbm_gbps": dm["gbps"],
                   "tokens_per_s": dm["tokens_per_s"], "launch": dm["launch"],
                   "roofline": {"bound": "hbm", "achieved": kb / t_kd / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": kb / t_kd / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                               "frac": kb / t_kd / 1e9 / HBM_PEAK_GBPS,
+                               "traffic": profiled_traffic(f"{dom}@T{Td}:" + ops.gemm_kernel_name(
+                                   Td, n_d, kin_d // SUB_DIM, 1, K_ENTRIES, SUB_DIM, 1, dtype, dom_parts,
+                                   packed=dom_packed)) if world == 1 else None,
                                "kernel": ops.gemm_kernel_name(Td, n_d, kin_d // SUB_DIM, 1, K_ENTRIES, SUB_DIM, 1, dtype,
                                                               dom_parts, packed=dom_packed) + ":" + dom,
                                "launch_us": t_kd * 1e6}}
