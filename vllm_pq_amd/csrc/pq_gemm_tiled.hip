@@ -11,7 +11,12 @@ hipError_t launch_gemm_tiled_fp16(const GemmArgs &a, hipStream_t stream);
 bool gemm_tiled_supported(const GemmArgs &a) {
     if (!a.packed) return false;
     if (!packable(a.parts, a.d, a.K, a.M, a.code_bytes)) return false;
-    if ((a.G * a.d) % 64) return false;   // activations are staged in whole 64-feature tiles
+    // activations are staged in whole 64-feature tiles, codes consumed in register pieces of TPP tiles
+    {
+        const int ks = ((16 / a.code_bytes) / a.M) * a.d / 8;          // k-steps per code chunk
+        const int spp = ks >= 8 ? ks / 4 : ks >= 4 ? ks / 2 : ks;      // k-steps per piece
+        if ((a.G * a.d) % (32 * spp)) return false;
+    }
     if ((reinterpret_cast<uintptr_t>(a.x) & 15) || (a.x_stride % 8)) return false;
     if ((reinterpret_cast<uintptr_t>(a.codes) & 15) || (reinterpret_cast<uintptr_t>(a.codebooks) & 15)) return false;
     return true;

@@ -6,7 +6,7 @@
 // weight is never staged: it is the MFMA A operand, and lane l's fragment (row l&15, k = 8(l>>4)..+7)
 // is one d=8 centroid (two d=4, four d=2), read with one ds_read_b128 from the replicated LDS
 // codebook image at the address the lane's code selects (see pq_gemm_stream_impl.cuh).  Only the
-// activations go through LDS: a [BT][64] tile per step, double buffered, XOR-swizzled so that the
+// activations go through LDS: a [BT][64] tile per step, written by LDS-DMA into a 3-deep ring, XOR-swizzled so that the
 // B-operand reads (16 tokens x 4 k-octets per wave-instruction) are bank-conflict free.  A gathered
 // A fragment is reused for WT token fragments, an activation fragment for WN weight fragments.
 //
@@ -36,7 +36,9 @@ __device__ inline uint32_t xt_off(int row, int slot) { return (uint32_t)row * 12
 // WAVES_T of the 8 waves lie along the token axis, the rest along the row axis; a wave owns WN weight
 // fragments x WT token fragments, so the block tile is (8/WAVES_T * WN * 16) rows x (WAVES_T * WT * 16)
 // tokens.
-template <typename AT, typename CodeT, int D, int M, int WAVES_T, int WN, int WT>
+// ABL (diagnostic builds only; 0 in the library): bit 0 skips the LDS store of the next tile and the
+// barrier, bit 1 the activation loads, bit 2 the epilogue stores, bit 3 the gathers.
+template <typename AT, typename CodeT, int D, int M, int WAVES_T, int WN, int WT, int ABL = 0>
 __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     const uint16_t *__restrict__ x, int T, int64_t x_stride, const u32x4 *__restrict__ packed,
     const uint16_t *__restrict__ codebooks, const uint16_t *__restrict__ scales, const uint16_t *__restrict__ bias,
@@ -51,7 +53,8 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     constexpr int BN = WAVES_N * WN * 16;            // weight rows per block
     constexpr int BT = WAVES_T * WT * 16;            // tokens per block
     constexpr int XT_BYTES = BT * TL_BK * 2;         // one activation tile
-    constexpr int XLOADS = XT_BYTES / 16 / TL_THREADS;   // 16-byte pieces per thread per tile
+    constexpr int NBUF = 3;                          // LDS buffers: one being read, two in flight
+    constexpr int PPW = BT / 64;                     // one-KiB pieces per wave per tile
     // The codes of a chunk are consumed in PIECES register pieces (a half or a quarter of a lane's 16
     // bytes), so that the next piece can be prefetched with few live registers.
     constexpr int SPP = KS >= 8 ? KS / 4 : KS >= 4 ? KS / 2 : KS;   // k-steps per code piece
@@ -60,10 +63,10 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     constexpr int TPP = SPP / 2;                     // 64-k tiles per piece
     typedef uint32_t piece_t __attribute__((ext_vector_type(PW)));
     static_assert(KS % 2 == 0, "a code chunk must cover whole 64-k tiles");
-    static_assert(XLOADS >= 1, "tile too small for the block");
+    static_assert(PPW >= 1, "tile too small for the block");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *xt = smem + ST_MAX_LDS_CB;        // two activation tiles behind the codebook image
+    unsigned char *xt = smem + ST_MAX_LDS_CB;        // NBUF activation tiles behind the codebook image
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -87,46 +90,40 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     const int nfr = (loc.nrows + 15) >> 4;           // valid fragments in this row tile
     const int f0 = loc.row0 >> 4;
 
-    // ---- codebook image (entries first: they are needed before the first gather) -----------------
+    // ---- activation tiles: LDS-DMA (global_load_lds), NBUF buffers, two tiles in flight ----------------
+    // A tile is [BT][64] 16-bit values = BT/8 one-KiB pieces of 8 rows; a wave-instruction writes one piece
+    // linearly (LDS address = piece base + lane*16), so the XOR swizzle goes on the per-lane SOURCE: LDS
+    // slot l%8 of row l/8 receives logical 16-byte slot (l%8) ^ (l/8) of that row.  Tokens past T read the
+    // last valid row (their outputs are never stored).
+    const int ntiles_k = Kin / TL_BK;                // Kin % (64*TPP) == 0, checked on the host
+    const int npieces = ntiles_k / TPP;
+    const unsigned char *xbase = reinterpret_cast<const unsigned char *>(x + (size_t)t0 * x_stride);
+    uint32_t goff[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        int row = (wave * PPW + j) * 8 + (lane >> 3);
+        row = t0 + row < T ? row : T - 1 - t0;
+        goff[j] = (uint32_t)row * (uint32_t)(x_stride * 2) + (uint32_t)(((lane & 7) ^ (lane >> 3)) << 4);
+    }
+    auto x_issue = [&](int kt, int buf) {            // tile kt -> buffer buf (both wave-uniform)
+        if constexpr (ABL & 2) return;
+        const uint32_t kb = (uint32_t)(kt < ntiles_k ? kt : ntiles_k - 1) * (TL_BK * 2);
+        unsigned char *dst = xt + buf * XT_BYTES + wave * (PPW * 1024);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(xbase + (goff[j] + kb)),
+                (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+    };
+    x_issue(0, 0);
+    x_issue(1, 1);
+
+    // ---- codebook image ---------------------------------------------------------------------------
     {
         CodebookImage<D, TL_THREADS> img;
         img.load(reinterpret_cast<const unsigned char *>(codebooks) + (size_t)loc.part * M * K * EB, M * K, R, tid);
         img.store(smem, M * K, R, tid);
     }
-
-    // ---- activation tile staging: thread -> XLOADS 16-byte pieces, 8 pieces per 128-byte row ------
-    // Loads are unconditional (clamped addresses) and nothing touches the loaded registers until
-    // x_store, so the loads stay in flight across the tile's MFMAs.  Tokens past T read the last valid
-    // row: their outputs are never stored.
-    u32x4 xs[XLOADS];
-    const int npieces = nchunks * PIECES;
-    const int ntiles_k = npieces * TPP;              // tiles walked (whole code pieces)
-    const int nvalid_k = Kin / TL_BK;                // Kin % 64 == 0 (checked on the host); tiles past it are zero
-    // byte offsets of this thread's pieces from the tile's first token row (block-local, fits 32 bits)
-    const unsigned char *xbase = reinterpret_cast<const unsigned char *>(x + (size_t)t0 * x_stride);
-    uint32_t xoff[XLOADS];
-#pragma unroll
-    for (int i = 0; i < XLOADS; ++i) {
-        const int piece = tid + i * TL_THREADS;
-        int row = piece >> 3;
-        row = t0 + row < T ? row : T - 1 - t0;
-        xoff[i] = (uint32_t)row * (uint32_t)(x_stride * 2) + (uint32_t)(piece & 7) * 16u;
-    }
-    auto x_load = [&](int kt) {
-        // tiles past Kin (padding of the last code piece) re-read the last valid tile; x_store zeroes them
-        const uint32_t kb = (uint32_t)(kt < nvalid_k ? kt : nvalid_k - 1) * (TL_BK * 2);
-#pragma unroll
-        for (int i = 0; i < XLOADS; ++i) xs[i] = *reinterpret_cast<const u32x4 *>(xbase + (xoff[i] + kb));
-    };
-    auto x_store = [&](int buf, int kt) {
-#pragma unroll
-        for (int i = 0; i < XLOADS; ++i) {
-            const int piece = tid + i * TL_THREADS;
-            u32x4 v = xs[i];
-            if (kt >= nvalid_k) v = u32x4{0, 0, 0, 0};
-            *reinterpret_cast<u32x4 *>(xt + buf * XT_BYTES + xt_off(piece >> 3, piece & 7)) = v;
-        }
-    };
 
     f32x4 acc[WN][WT];
 #pragma unroll
@@ -138,8 +135,8 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     const uint32_t lane_off = (uint32_t)(lane & (R - 1)) * EB;
     const uint32_t cb_stride = (uint32_t)K * EB * R;
 
-    x_load(0);
-    x_store(0, 0);
+    // everything issued so far (two tiles, the image) has landed before the first read
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // fragment bases are wave-uniform (scalar registers); the per-lane part is one 32-bit offset
@@ -155,17 +152,30 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
 #pragma unroll
         for (int i = 0; i < WN; ++i) dst[i] = *reinterpret_cast<const piece_t *>(fbase[i] + off);
     };
-    // No branch around any load in the loop: a conditional load makes hipcc drain vmcnt at the join, which
-    // would expose the whole global-load latency in every tile.  The last piece / tile re-loads itself.
+    // Per tile: issue the DMA of tile kt+2, compute tile kt, wait until only those newest PPW DMAs are
+    // outstanding (tile kt+1 has landed for this wave), barrier (landed for every wave; and everybody
+    // is done reading tile kt, whose buffer the next iteration's DMA overwrites).  No branch around a
+    // load and no __syncthreads() in the loop: either would drain vmcnt and stall the DMA pipeline.
     piece_t cw[WN], cwn[WN];
     load_piece(cw, 0);
+    // consume the first piece's registers here, so that the compiler waits for these loads before the
+    // loop and not (with vmcnt(0), draining the DMA just issued) at the loop head
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+#pragma unroll
+        for (int w = 0; w < PW; ++w) {
+            uint32_t t = cw[i][w];
+            asm volatile("" : "+v"(t));
+            cw[i][w] = t;
+        }
+    }
+    int buf = 0, buf2 = 2;
     for (int p = 0; p < npieces; ++p) {
-        load_piece(cwn, p + 1 < npieces ? p + 1 : p);  // in flight during this piece's TPP tiles
+        load_piece(cwn, p + 1 < npieces ? p + 1 : p);  // older than this piece's DMAs: landed by the first wait
 #pragma unroll
         for (int it = 0; it < TPP; ++it) {
             const int kt = p * TPP + it;
-            const int buf = kt & 1;
-            x_load(kt + 1 < ntiles_k ? kt + 1 : kt);
+            x_issue(kt + 2, buf2);
             const unsigned char *xb = xt + buf * XT_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -185,15 +195,26 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
 #pragma unroll
                         for (int u = 0; u < CPS; ++u)
                             idx[u] = code_at<CB>(cw[i], (s * CPS + u) * M + m, (uint32_t)nbits);
-                        const vec8 am = gather_frag<AT, D>(smem + m * cb_stride, idx, shift, lane_off);
+                        vec8 am;
+                        if constexpr (ABL & 8) {
+                            const u32x4 fake{idx[0], idx[0] + 1, idx[0] ^ 5, idx[0] * 3};
+                            am = __builtin_bit_cast(vec8, fake);
+                        } else {
+                            am = gather_frag<AT, D>(smem + m * cb_stride, idx, shift, lane_off);
+                        }
                         a = m == 0 ? am : Act<AT>::add8(a, am);
                     }
 #pragma unroll
                     for (int j = 0; j < WT; ++j) acc[i][j] = Act<AT>::mfma16(a, xf[j], acc[i][j]);
                 }
             }
-            x_store(buf ^ 1, kt + 1);                   // after the last tile nobody reads it
-            __syncthreads();
+            if constexpr (!(ABL & 1)) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            buf = buf == NBUF - 1 ? 0 : buf + 1;
+            buf2 = buf2 == NBUF - 1 ? 0 : buf2 + 1;
         }
 #pragma unroll
         for (int i = 0; i < WN; ++i) cw[i] = cwn[i];
@@ -219,6 +240,10 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[r] = Act<AT>::from_f32(acc[i][j][r] * sc[r] + bi[r]);
             uint16_t *yp = y + (size_t)t * y_stride + nb;
+            if constexpr (ABL & 4) {
+                if (h[0] == 0x1234 && h[1] == 0x4321 && h[2] == 0x1111) yp[0] = h[3];   // keeps acc live
+                continue;
+            }
             if (nb + 4 <= row_end && (reinterpret_cast<uintptr_t>(yp) & 7) == 0) {
                 u32x2 o2;
                 o2.x = h[0] | ((uint32_t)h[1] << 16);
@@ -244,7 +269,7 @@ static hipError_t tiled_launch_cfg(const GemmArgs &a, hipStream_t stream) {
     const int t_tiles = (a.T + BT - 1) / BT;
     const int total = n_tiles * t_tiles;
     const int per_xcd = (total + 7) / 8;
-    const size_t lds = (size_t)ST_MAX_LDS_CB + 2 * (size_t)BT * TL_BK * 2;
+    const size_t lds = (size_t)ST_MAX_LDS_CB + 3 * (size_t)BT * TL_BK * 2;
     auto kern = gemm_tiled_kernel<AT, CodeT, D, M, WAVES_T, WN, WT>;
     static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
