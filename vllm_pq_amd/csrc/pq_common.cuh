@@ -63,6 +63,53 @@ __device__ inline TileLoc locate_tile(const Parts &P, int tile, int rows_per_til
     return L;
 }
 
+// The same map with the per-partition prefix sums worked out on the host, so that a block finds its
+// tile with a handful of scalar compare/selects instead of a division loop over the partitions (that
+// loop is ~300 dependent scalar instructions, over a microsecond at the head of a short kernel).
+struct TileMap {
+    int tile0[PQ_MAX_PARTS];    // first tile of partition p (INT_MAX for p >= num)
+    int row0[PQ_MAX_PARTS];     // first row of partition p
+    int row_end[PQ_MAX_PARTS];  // one past its last row
+};
+
+inline TileMap make_tile_map(const Parts &P, int rows_per_tile) {
+    TileMap m;
+    int tile = 0, row = 0;
+    for (int p = 0; p < PQ_MAX_PARTS; ++p) {
+        if (p < P.num) {
+            m.tile0[p] = tile;
+            m.row0[p] = row;
+            row += P.size[p];
+            m.row_end[p] = row;
+            tile += (P.size[p] + rows_per_tile - 1) / rows_per_tile;
+        } else {
+            m.tile0[p] = 0x7fffffff;
+            m.row0[p] = row;
+            m.row_end[p] = row;
+        }
+    }
+    return m;
+}
+
+__device__ inline TileLoc locate_tile(const TileMap &m, int tile, int rows_per_tile) {
+    int part = 0, t0 = m.tile0[0], r0 = m.row0[0], re = m.row_end[0];
+#pragma unroll
+    for (int p = 1; p < PQ_MAX_PARTS; ++p) {
+        const bool ge = tile >= m.tile0[p];
+        part = ge ? p : part;
+        t0 = ge ? m.tile0[p] : t0;
+        r0 = ge ? m.row0[p] : r0;
+        re = ge ? m.row_end[p] : re;
+    }
+    TileLoc L;
+    L.part = part;
+    L.row0 = r0 + (tile - t0) * rows_per_tile;
+    const int left = re - L.row0;
+    L.nrows = left < rows_per_tile ? left : rows_per_tile;
+    return L;
+}
+
+
 // ---- act dtype traits ---------------------------------------------------------------------
 template <typename AT>
 struct Act;

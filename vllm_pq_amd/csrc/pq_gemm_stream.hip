@@ -6,6 +6,9 @@
 // (lane & 15) and q = k quad (lane >> 4).  Code position (s*CPS + u)*M + m of the lane's 16 bytes is
 // codes[16 f + r][c*CG + 4*CPS*s + CPS*q + u][m] (zero past G), so that MFMA k-step s of the chunk
 // covers the 32 consecutive input features starting at (c*CG)*d + 32 s.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "pq_common.cuh"
 #include "pq_kernels.h"
 #include "pq_stream_geom.cuh"
@@ -38,6 +41,63 @@ bool gemm_stream_supported(const GemmArgs &a) {
     return a.G % gpl == 0 && !(reinterpret_cast<uintptr_t>(a.codes) & 15);
 }
 
+
+// ---- tile shape --------------------------------------------------------------------------------------
+// {NF weight fragments, TF token fragments} per block.  Every block re-reads its k-range of the
+// activations from L2, so more rows per block means less L2 traffic for x, and more token fragments
+// mean more MFMAs per gathered weight fragment; fewer rows / tokens per block mean more blocks in
+// flight.  `light` formats (d = 8, one codebook, one-byte codes) need the fewest registers per fragment;
+// the others (several gathers or a rounding add per operand) keep tiles small enough not to spill.
+static bool stream_light_format(const GemmArgs &a) { return a.d == 8 && a.M == 1 && a.code_bytes == 1; }
+
+// Duration model of one launch in microseconds, fitted on the MI355X for 17 <= T <= 512: the blocks run
+// in rounds of one per CU; a block costs a fixed 4 us (launch, codebook image, first loads, cross-wave
+// sum) plus 0.95 us per (chunk of one wave) x (accumulator fragment): with more than 16 tokens the
+// activation loads from L2, only one sub-chunk ahead, set the pace, not the code stream.
+static double stream_model_us(const GemmArgs &a, int nf, int tf) {
+    const int cg = chunk_groups(a.code_bytes, a.M);
+    const double nchunks = (double)((a.G + cg - 1) / cg);
+    const long blocks = (long)tiles_in(a.parts, nf * 16) * ((a.T + 16 * tf - 1) / (16 * tf));
+    const double rounds = (double)((blocks + 255) / 256);
+    const double per_wave = nchunks / 8.0 < 1.0 ? 1.0 : nchunks / 8.0;
+    return rounds * (4.0 + per_wave * nf * tf * 0.95);
+}
+
+StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {
+    const bool light = stream_light_format(a), packed = a.packed;
+    if (model_us) *model_us = 0.0;
+    const char *env = getenv("PQ_AMD_STREAM_CFG");   // "NFxTF", for tuning
+    if (env && *env) {
+        int nf = 0, tf = 0;
+        if (sscanf(env, "%dx%d", &nf, &tf) == 2) {
+            const bool ok1 = tf == 1 && (nf == 1 || nf == 2 || (light && (nf == 4 || (packed && (nf == 7 || nf == 8)))));
+            const bool okw = packed && ((nf == 4 && tf == 4 && light) || (nf == 4 && tf == 2) || (nf == 2 && tf == 4));
+            if (ok1 || okw) return StreamCfg{nf, tf};
+        }
+    }
+    if (!packed || a.T <= 16) {
+        // one token fragment: the code stream from HBM is the bound; about one block per CU
+        static const int cand[] = {8, 7, 4, 2, 1};
+        for (int nf : cand) {
+            if (nf > 2 && !light) continue;
+            if (nf > 4 && !packed) continue;
+            if (tiles_in(a.parts, nf * 16) >= 224) return StreamCfg{nf, 1};
+        }
+        return StreamCfg{1, 1};
+    }
+    // 17 tokens and more: the shape with the shortest modelled launch
+    static const StreamCfg wide[] = {{4, 4}, {2, 4}, {4, 2}};
+    StreamCfg best = wide[2];
+    double best_us = -1.0;
+    for (const StreamCfg &c : wide) {
+        if (c.nf == 4 && c.tf == 4 && !light) continue;
+        if (c.tf == 4 && a.T <= 32) continue;   // half the token tile would be padding
+        const double us = stream_model_us(a, c.nf, c.tf);
+        if (best_us < 0.0 || us < best_us) { best_us = us; best = c; }
+    }
+    if (model_us) *model_us = best_us;
+    return best;
+}
 
 hipError_t launch_gemm_stream_bf16(const GemmArgs &a, hipStream_t stream);
 hipError_t launch_gemm_stream_fp16(const GemmArgs &a, hipStream_t stream);

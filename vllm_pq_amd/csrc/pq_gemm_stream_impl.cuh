@@ -1,4 +1,4 @@
-// Fused codebook gather + MFMA GEMM for small token counts (decode) on gfx950.
+// Fused codebook gather + MFMA GEMM for small and medium token counts (decode batches) on gfx950.
 //
 // y[t][n] = scale[n] * sum_k x[t][k] * W[n][k] + bias[n],   W[n][8g..8g+7] = centroid(code[n][g])
 //
@@ -10,10 +10,14 @@
 // x[t = l&15][the same 8 k]) and stay in registers: they are loaded once per k-chunk and reused by
 // every weight fragment of the tile.  A 16x16 accumulator holds y^T for 16 rows x 16 tokens.
 //
-// Work split.  A block owns NF fragments (16*NF weight rows of one output partition) and all of K;
-// its waves split K in chunks (one chunk = what a lane's 16-byte code load covers, times 4 lane
-// quads), each wave streaming its codes from HBM with 16-byte loads.  Partial accumulators of the
-// waves are summed in a fixed order through LDS (deterministic), then scaled, biased and stored.
+// Work split.  A block owns NF weight fragments (16*NF rows of one output partition) x TF token
+// fragments (16*TF tokens) and all of K; its 8 waves split K in chunks (one chunk = what a lane's
+// 16-byte code load covers, times 4 lane quads), each wave streaming its codes from HBM with 16-byte
+// loads and its slice of the activations from L2 straight into registers (32 registers at a time,
+// one sub-chunk ahead).  There is no barrier in the main loop.  A gathered weight fragment feeds TF
+// MFMAs, an activation fragment NF.  The partial accumulators of the waves are summed in a fixed order
+// through LDS (deterministic), then scaled, biased and stored; scales and bias are fetched at kernel
+// start so that no global load sits on the tail.
 //
 // Code layouts.  NATURAL is the reference's [N][G][M]: a lane's 16 bytes are 16 consecutive groups of
 // its row, so MFMA k-step s of lane quad q covers groups 16q+s and the matching activation loads are
@@ -26,8 +30,6 @@
 // R = 16 (d=8), 32 (d=4, d=2) every lane of an LDS lane group reads a different bank slot whatever
 // the codes are, so the gather runs at the conflict-free ds_read rate.
 #pragma once
-#include <stdlib.h>
-
 #include "pq_common.cuh"
 #include "pq_kernels.h"
 #include "pq_gather.cuh"
@@ -40,58 +42,68 @@ constexpr int ST_WAVES = ST_THREADS / 64;
 
 // ABL (diagnostic builds only; 0 in the library): bit 0 skips the LDS gather, bit 1 the MFMAs, bit 2 the
 // code loads, bit 3 the activation loads, bit 4 the codebook image, bit 5 the cross-wave sum + stores.
-template <typename AT, typename CodeT, int D, int M, int NF, bool PACKED, int ABL = 0>
+template <typename AT, typename CodeT, int D, int M, int NF, int TF, bool PACKED, int ABL = 0>
 __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
     const uint16_t *__restrict__ x, int T, int64_t x_stride, const void *__restrict__ codes_v,
     const uint16_t *__restrict__ codebooks, const uint16_t *__restrict__ scales, const uint16_t *__restrict__ bias,
-    Parts parts, int G, int K, int nbits, int R, uint16_t *__restrict__ y, int64_t y_stride) {
+    TileMap tmap, int G, int K, int nbits, int R, uint16_t *__restrict__ y, int64_t y_stride) {
     typedef typename Act<AT>::vec8 vec8;
     typedef StreamFmt<sizeof(CodeT), D, M> F;
     constexpr int CB = sizeof(CodeT);
     constexpr int EB = 2 * D;
     constexpr int GPL = F::GPL, CG = F::CG, KS = F::KS, CPS = F::CPS;
+    constexpr int SUBK = (8 / TF) < KS ? (8 / TF) : KS;   // k-steps per activation sub-load: <= 32 registers
+    constexpr int NSUB = KS / SUBK;
+    constexpr int FR = NF * TF;                            // accumulator fragments per wave
+    constexpr int RF = FR < 8 ? FR : 8;                    // fragments per reduction round (<= 64 KiB of LDS)
+    constexpr int ROUNDS = FR / RF;
+    static_assert(KS % SUBK == 0 && FR % RF == 0, "unsupported tile shape");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15;   // weight row within a fragment (A) / token within the chunk (B)
+    // ABL bit 6 (diagnostic build): thread 0 of every block writes wall-clock stamps of the phases into
+    // the buffer passed as `bias` (8 x u64 per block); such a build computes no usable output.
+    unsigned long long *stamps = nullptr;
+    if constexpr (ABL & 64) {
+        stamps = reinterpret_cast<unsigned long long *>(const_cast<uint16_t *>(bias)) +
+                 (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        bias = nullptr;
+        if (tid == 0) stamps[0] = wall_clock64();
+    }
+    const int r16 = lane & 15;   // weight row within a fragment (A) / token within a fragment (B)
     const int q = lane >> 4;     // k quad
 
-    const TileLoc loc = locate_tile(parts, blockIdx.x, NF * 16);
-    const int t0 = blockIdx.y * 16;
+    const TileLoc loc = locate_tile(tmap, blockIdx.x, NF * 16);
+    const int t0 = blockIdx.y * (16 * TF);
     const int row_end = loc.row0 + loc.nrows;
     const int Kin = G * D;
-
-    f32x4 acc[NF];
-#pragma unroll
-    for (int i = 0; i < NF; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     const int nchunks = (G + CG - 1) / CG;
+
+    f32x4 acc[NF][TF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < TF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     // Tokens past T read the last valid token's row (same addresses, so no extra traffic) and are
     // zeroed with a select: no divergent branch around any load.
-    const bool tok_ok = (t0 + r16) < T;
-    const int trow = tok_ok ? t0 + r16 : T - 1;
-    const uint16_t *xrow = x + (size_t)trow * x_stride;
-
-    // One chunk of this wave's work in registers: NF code pieces + KS activation fragments.
-    struct Chunk {
-        u32x4 cw[NF];
-        vec8 xf[KS];
-    };
-    auto load_chunk = [&](Chunk &ch, int c) {
-        if constexpr (PACKED) {
+    bool tok_ok[TF];
+    const uint16_t *xrow[TF];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int k = c * (CG * D) + 32 * s + 8 * q;   // k-step s covers 32 consecutive k
-                const bool ok = tok_ok && k < Kin;
-                u32x4 v;
-                if constexpr (ABL & 8) v = u32x4{(uint32_t)k, 1u, 2u, (uint32_t)lane};
-                else v = *reinterpret_cast<const u32x4 *>(xrow + (k < Kin ? k : 0));
-                if (!ok) v = u32x4{0, 0, 0, 0};
-                ch.xf[s] = __builtin_bit_cast(vec8, v);
-            }
+    for (int j = 0; j < TF; ++j) {
+        const int t = t0 + 16 * j + r16;
+        tok_ok[j] = t < T;
+        xrow[j] = x + (size_t)(t < T ? t : T - 1) * x_stride;
+    }
+
+    struct Codes { u32x4 cw[NF]; };
+    struct XSub { vec8 f[SUBK][TF]; };
+
+    auto load_codes = [&](Codes &cd, int c) {
+        if constexpr (PACKED) {
             // [fragment][chunk][lane] 16-byte pieces; fragments are 16 absolute rows
             const u32x4 *pk = static_cast<const u32x4 *>(codes_v);
             const int f0 = loc.row0 >> 4;
@@ -99,26 +111,39 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
                 const int f = f0 + (i < nfr ? i : nfr - 1);   // clamp: rows past the tile are never stored
-                if constexpr (ABL & 4) ch.cw[i] = u32x4{(uint32_t)(f * 977 + lane), (uint32_t)c, (uint32_t)lane * 31, 7u};
-                else ch.cw[i] = __builtin_nontemporal_load(&pk[((size_t)f * nchunks + c) * 64 + lane]);
+                if constexpr (ABL & 4) cd.cw[i] = u32x4{(uint32_t)(f * 977 + lane), (uint32_t)c, (uint32_t)lane * 31, 7u};
+                else cd.cw[i] = __builtin_nontemporal_load(&pk[((size_t)f * nchunks + c) * 64 + lane]);
             }
         } else {
             const CodeT *codes = static_cast<const CodeT *>(codes_v);
             const int g0 = c * CG + GPL * q;           // first input group of this lane
-            const bool g_ok = g0 < G;                  // G % GPL == 0: all-or-nothing per lane
-            const int g0c = g_ok ? g0 : 0;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                u32x4 v = *reinterpret_cast<const u32x4 *>(xrow + (size_t)g0c * D + 8 * s);
-                if (!(g_ok && tok_ok)) v = u32x4{0, 0, 0, 0};
-                ch.xf[s] = __builtin_bit_cast(vec8, v);
-            }
+            const int g0c = g0 < G ? g0 : 0;           // G % GPL == 0: all-or-nothing per lane
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
                 int n = loc.row0 + 16 * i + r16;
                 n = n < row_end ? n : row_end - 1;
-                ch.cw[i] = __builtin_nontemporal_load(
+                cd.cw[i] = __builtin_nontemporal_load(
                     reinterpret_cast<const u32x4 *>(codes + ((size_t)n * G + g0c) * M));
+            }
+        }
+    };
+    // activation fragments of k-steps sub*SUBK .. +SUBK-1 of chunk c
+    auto load_x = [&](XSub &xs, int c, int sub) {
+#pragma unroll
+        for (int s = 0; s < SUBK; ++s) {
+            int k;
+            if constexpr (PACKED) k = c * (CG * D) + 32 * (sub * SUBK + s) + 8 * q;   // 32 consecutive k per step
+            else k = (c * CG + GPL * q) * D + 8 * (sub * SUBK + s);                 // the lane's own 16 groups
+            const bool k_ok = k < Kin;
+#pragma unroll
+            for (int j = 0; j < TF; ++j) {
+                u32x4 v;
+                if constexpr (ABL & 8) v = u32x4{(uint32_t)k, 1u, 2u, (uint32_t)lane};
+                else v = *reinterpret_cast<const u32x4 *>(xrow[j] + (k_ok ? k : 0));
+                // zeroing by mask, not by select: a select lets the compiler sink the load into a branch
+                const uint32_t keep = 0u - (uint32_t)(k_ok && tok_ok[j]);
+                v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+                xs.f[s][j] = __builtin_bit_cast(vec8, v);
             }
         }
     };
@@ -126,21 +151,22 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
     const uint32_t shift = (uint32_t)__builtin_ctz((unsigned)(EB * R));   // log2 of the entry stride
     const uint32_t lane_off = (uint32_t)(lane & (R - 1)) * EB;
     const uint32_t cb_stride = (uint32_t)K * EB * R;                       // bytes per codebook image
-    auto compute_chunk = [&](const Chunk &ch) {
+    auto compute_sub = [&](const Codes &cd, const XSub &xs, int sub) {
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
+            for (int s = 0; s < SUBK; ++s) {
+                const int ss = sub * SUBK + s;   // k-step within the chunk
                 vec8 a;
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     uint32_t idx[CPS];
 #pragma unroll
                     for (int u = 0; u < CPS; ++u)
-                        idx[u] = code_at<CB>(ch.cw[i], (s * CPS + u) * M + m, (uint32_t)nbits);
+                        idx[u] = code_at<CB>(cd.cw[i], (ss * CPS + u) * M + m, (uint32_t)nbits);
                     vec8 am;
                     if constexpr (ABL & 1) {
-                        u32x4 fake{idx[0], idx[0] + 1, idx[0] ^ 5, idx[0] * 3};
+                        u32x4 fake{idx[0], 0u, 0u, 0u};
                         am = __builtin_bit_cast(vec8, fake);
                     } else {
                         am = gather_frag<AT, D>(smem + m * cb_stride, idx, shift, lane_off);
@@ -150,154 +176,181 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
                     // gemm_kernels.cu:169)
                     a = m == 0 ? am : Act<AT>::add8(a, am);
                 }
-                if constexpr (ABL & 2) {
-                    const u32x4 au = __builtin_bit_cast(u32x4, a), xu = __builtin_bit_cast(u32x4, ch.xf[s]);
-                    acc[i].x += __uint_as_float(au.x ^ xu.x);   // keeps the operands live
-                    acc[i].y += __uint_as_float(au.y ^ xu.y);
-                    acc[i].z += __uint_as_float(au.z ^ xu.z);
-                    acc[i].w += __uint_as_float(au.w ^ xu.w);
-                } else {
-                    acc[i] = Act<AT>::mfma16(a, ch.xf[s], acc[i]);
+#pragma unroll
+                for (int j = 0; j < TF; ++j) {
+                    if constexpr (ABL & 2) {
+                        const u32x4 au = __builtin_bit_cast(u32x4, a), xu = __builtin_bit_cast(u32x4, xs.f[s][j]);
+                        acc[i][j].x = __uint_as_float(__float_as_uint(acc[i][j].x) ^ au.x ^ au.y ^ xu.x);
+                    } else {
+                        acc[i][j] = Act<AT>::mfma16(a, xs.f[s][j], acc[i][j]);
+                    }
                 }
             }
         }
     };
 
-    // ---- this wave's first chunk goes out before the codebook image is built --------------------
-    // Issue order = return order: codebook entries (L2), activations (L2), then the codes (HBM).
+    // ---- everything the first chunk needs is requested before anything is waited for: the codebook
+    // entries (needed first), the wave's first codes (HBM, the long latency), its first activations (L2)
     CodebookImage<D, ST_THREADS> img;
     if constexpr (!(ABL & 16))
         img.load(reinterpret_cast<const unsigned char *>(codebooks) + (size_t)loc.part * M * K * EB, M * K, R, tid);
-    Chunk A, B;
-    if (wave < nchunks) load_chunk(A, wave);
+    Codes cA, cB;
+    XSub X[2];
+    if (wave < nchunks) {
+        load_codes(cA, wave);
+        load_x(X[0], wave, 0);
+    }
+    // ---- epilogue operands: this thread's output rows in each reduction round.  Fetched now, behind the
+    // streaming loads and without touching the loaded registers, so that no global load sits on the tail.
+    // round r, thread -> fragment fr = r*RF + tid/64 = (i, j) = (fr / TF, fr % TF); lane l of it holds
+    // token 16 j + (l & 15) and rows 16 i + 4 (l >> 4) .. + 3
+    uint16_t sc_raw[ROUNDS][4], bi_raw[ROUNDS][4];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int i = (r * RF + (tid >> 6)) / TF;
+        const int nb = loc.row0 + 16 * i + q * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = nb + e < row_end ? nb + e : row_end - 1;
+            sc_raw[r][e] = scales[n];
+            bi_raw[r][e] = bias ? bias[n] : (uint16_t)0;
+        }
+    }
+    if constexpr (ABL & 64) if (tid == 0) stamps[1] = wall_clock64();   // loads issued
     if constexpr (!(ABL & 16)) img.store(smem, M * K, R, tid);
     __syncthreads();
+    if constexpr (ABL & 64) if (tid == 0) stamps[2] = wall_clock64();   // image built
 
-    // ---- chunks wave, wave + 8, ...: the next chunk's loads are in flight while one is computed ---
+    // ---- chunks wave, wave + 8, ...: two per iteration so that every register set has a fixed name.
+    // The next sub-chunk's activations and the next chunk's codes are in flight while one is computed.
     for (int c = wave; c < nchunks; c += 2 * ST_WAVES) {
-        const bool more1 = c + ST_WAVES < nchunks;
-        if (more1) load_chunk(B, c + ST_WAVES);
-        compute_chunk(A);
-        if (more1) {
-            if (c + 2 * ST_WAVES < nchunks) load_chunk(A, c + 2 * ST_WAVES);
-            compute_chunk(B);
+        const int c1 = c + ST_WAVES, c2 = c + 2 * ST_WAVES;
+        const bool m1 = c1 < nchunks, m2 = c2 < nchunks;
+        if (m1) load_codes(cB, c1);
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            if (sub + 1 < NSUB) load_x(X[(sub + 1) & 1], c, sub + 1);
+            else if (m1) load_x(X[(sub + 1) & 1], c1, 0);
+            compute_sub(cA, X[sub & 1], sub);
+        }
+        if (m1) {
+            if (m2) load_codes(cA, c2);
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                if (sub + 1 < NSUB) load_x(X[(NSUB + sub + 1) & 1], c1, sub + 1);
+                else if (m2) load_x(X[(NSUB + sub + 1) & 1], c2, 0);
+                compute_sub(cB, X[(NSUB + sub) & 1], sub);
+            }
         }
     }
 
     if constexpr (ABL & 32) {
         float v = 0.f;
 #pragma unroll
-        for (int i = 0; i < NF; ++i) v += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < TF; ++j) v += acc[i][j].x + acc[i][j].y + acc[i][j].z + acc[i][j].w;
         if (v == 123.456f) y[tid] = 1;    // keeps the accumulators live, practically never stores
         return;
     }
-    // ---- deterministic cross-wave sum through LDS (the codebook image is dead now) -------------
-    __syncthreads();
-    f32x4 *red = reinterpret_cast<f32x4 *>(smem);   // [wave][NF][64]
+
+    if constexpr (ABL & 64) {
+        asm volatile("s_nop 0" :: "v"(acc[0][0].x));
+        if (tid == 0) stamps[3] = wall_clock64();   // this wave's MFMAs done
+    }
+    // ---- deterministic cross-wave sum through LDS (the codebook image is dead now), RF fragments a round
+    f32x4 *red = reinterpret_cast<f32x4 *>(smem);   // [wave][RF][64]
 #pragma unroll
-    for (int i = 0; i < NF; ++i) red[(wave * NF + i) * 64 + lane] = acc[i];
-    __syncthreads();
-    for (int o = tid; o < NF * 64; o += ST_THREADS) {
-        const int i = o >> 6;
-        const int l = o & 63;
-        f32x4 sum = red[i * 64 + l];
+    for (int r = 0; r < ROUNDS; ++r) {
+        __syncthreads();
 #pragma unroll
-        for (int w = 1; w < ST_WAVES; ++w) {
-            const f32x4 v = red[(w * NF + i) * 64 + l];
-            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        for (int f = 0; f < RF; ++f) {
+            const int fr = r * RF + f;
+            red[(wave * RF + f) * 64 + lane] = acc[fr / TF][fr % TF];
         }
-        // accumulator map: column (token) = l & 15, row = (l >> 4) * 4 + reg
-        const int t = t0 + (l & 15);
-        const int nb = loc.row0 + 16 * i + (l >> 4) * 4;
-        if (t < T && nb < row_end) {
-            uint16_t *yp = y + (size_t)t * y_stride + nb;
-            if (nb + 4 <= row_end && ((reinterpret_cast<uintptr_t>(yp) & 7) == 0) &&
-                ((reinterpret_cast<uintptr_t>(scales + nb) & 7) == 0)) {
-                const u32x2 sv = *reinterpret_cast<const u32x2 *>(scales + nb);
-                u32x2 bv{0, 0};
-                if (bias) {
-                    bv.x = bias[nb] | ((uint32_t)bias[nb + 1] << 16);
-                    bv.y = bias[nb + 2] | ((uint32_t)bias[nb + 3] << 16);
-                }
+        __syncthreads();
+        if constexpr (ABL & 64) if (tid == 0 && r == 0) stamps[4] = wall_clock64();   // all waves done
+        if (tid < RF * 64) {
+            const int f = tid >> 6;
+            f32x4 sum = red[f * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < ST_WAVES; ++w) {
+                const f32x4 v = red[(w * RF + f) * 64 + lane];
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            // accumulator map: column (token) = lane & 15, row = (lane >> 4) * 4 + reg
+            const int fr = r * RF + f;
+            const int t = t0 + 16 * (fr % TF) + r16;
+            const int nb = loc.row0 + 16 * (fr / TF) + q * 4;
+            if (t < T && nb < row_end) {
                 uint16_t h[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t sw = r < 2 ? sv.x : sv.y, bw = r < 2 ? bv.x : bv.y;
-                    const float s = Act<AT>::to_f32((uint16_t)(sw >> ((r & 1) * 16)));
-                    const float b = Act<AT>::to_f32((uint16_t)(bw >> ((r & 1) * 16)));
-                    h[r] = Act<AT>::from_f32(sum[r] * s + b);
-                }
-                u32x2 o2;
-                o2.x = h[0] | ((uint32_t)h[1] << 16);
-                o2.y = h[2] | ((uint32_t)h[3] << 16);
-                *reinterpret_cast<u32x2 *>(yp) = o2;
-            } else {
+                for (int e = 0; e < 4; ++e)
+                    h[e] = Act<AT>::from_f32(sum[e] * Act<AT>::to_f32(sc_raw[r][e]) + Act<AT>::to_f32(bi_raw[r][e]));
+                uint16_t *yp = y + (size_t)t * y_stride + nb;
+                if (nb + 4 <= row_end && (reinterpret_cast<uintptr_t>(yp) & 7) == 0) {
+                    u32x2 o2;
+                    o2.x = h[0] | ((uint32_t)h[1] << 16);
+                    o2.y = h[2] | ((uint32_t)h[3] << 16);
+                    *reinterpret_cast<u32x2 *>(yp) = o2;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (nb + r < row_end) {
-                        const float s = Act<AT>::to_f32(scales[nb + r]);
-                        const float b = bias ? Act<AT>::to_f32(bias[nb + r]) : 0.f;
-                        yp[r] = Act<AT>::from_f32(sum[r] * s + b);
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        if (nb + e < row_end) yp[e] = h[e];
                 }
             }
         }
     }
+    if constexpr (ABL & 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) stamps[5] = wall_clock64();   // stores retired
+    }
 }
 
 // ---- per-dtype launcher (instantiated once per act dtype, in its own translation unit) --------
-template <typename AT, typename CodeT, int D, int M, int NF, bool PACKED>
+template <typename AT, typename CodeT, int D, int M, int NF, int TF, bool PACKED>
 static hipError_t launch_nf(const GemmArgs &a, hipStream_t stream) {
     const int R = stream_replication<D>(a.K, a.M);
     const int nbits = __builtin_ctz((unsigned)a.K);
+    constexpr int RF = NF * TF < 8 ? NF * TF : 8;
     size_t lds = (size_t)a.M * a.K * 2 * D * R;
-    const size_t red = (size_t)ST_WAVES * NF * 64 * 16;
+    const size_t red = (size_t)ST_WAVES * RF * 64 * 16;
     if (red > lds) lds = red;
-    const dim3 grid(tiles_in(a.parts, NF * 16), (a.T + 15) / 16);
-    hipLaunchKernelGGL((gemm_stream_kernel<AT, CodeT, D, M, NF, PACKED>), grid, dim3(ST_THREADS), lds, stream,
+    const dim3 grid(tiles_in(a.parts, NF * 16), (a.T + 16 * TF - 1) / (16 * TF));
+    hipLaunchKernelGGL((gemm_stream_kernel<AT, CodeT, D, M, NF, TF, PACKED>), grid, dim3(ST_THREADS), lds, stream,
                        static_cast<const uint16_t *>(a.x), a.T, a.x_stride, a.codes,
                        static_cast<const uint16_t *>(a.codebooks), static_cast<const uint16_t *>(a.scales),
-                       static_cast<const uint16_t *>(a.bias), a.parts, a.G, a.K, nbits, R,
+                       static_cast<const uint16_t *>(a.bias), make_tile_map(a.parts, NF * 16), a.G, a.K, nbits, R,
                        static_cast<uint16_t *>(a.y), a.y_stride);
     return hipGetLastError();
 }
 
-// Rows per block.  Every block re-reads its k-range of the activations, so more rows per block means
-// less L2 traffic for x; fewer rows means more blocks in flight.  Aim at one block per CU and cap the
-// x : codes byte ratio, which grows with the number of valid tokens.
-static int choose_nf(const GemmArgs &a, bool packed) {
-    const char *env = getenv("PQ_AMD_STREAM_NF");
-    if (env && *env) {
-        const int v = atoi(env);
-        if (v == 1 || v == 2 || v == 4 || (packed && (v == 7 || v == 8))) return v;
-    }
-    if (!packed) {
-        if (tiles_in(a.parts, 64) >= 240) return 4;
-        if (tiles_in(a.parts, 32) >= 240) return 2;
-        return 1;
-    }
-    static const int cand[] = {8, 7, 4, 2, 1};
-    for (int nf : cand)
-        if (tiles_in(a.parts, nf * 16) >= 224) return nf;
-    return 1;
-}
-
 template <typename AT, typename CodeT, int D, int M>
 static hipError_t launch_fmt(const GemmArgs &a, hipStream_t stream) {
+    constexpr bool LIGHT = D == 8 && M == 1 && sizeof(CodeT) == 1;   // == stream_light_format(a)
+    const StreamCfg c = choose_stream_cfg(a, nullptr);
     if (a.packed) {
-        switch (choose_nf(a, true)) {
-        case 8: return launch_nf<AT, CodeT, D, M, 8, true>(a, stream);
-        case 7: return launch_nf<AT, CodeT, D, M, 7, true>(a, stream);
-        case 4: return launch_nf<AT, CodeT, D, M, 4, true>(a, stream);
-        case 2: return launch_nf<AT, CodeT, D, M, 2, true>(a, stream);
-        default: return launch_nf<AT, CodeT, D, M, 1, true>(a, stream);
+        if (c.tf == 4) {
+            if constexpr (LIGHT)
+                if (c.nf == 4) return launch_nf<AT, CodeT, D, M, 4, 4, true>(a, stream);
+            return launch_nf<AT, CodeT, D, M, 2, 4, true>(a, stream);
         }
+        if (c.tf == 2) return launch_nf<AT, CodeT, D, M, 4, 2, true>(a, stream);
+        if constexpr (LIGHT) {
+            switch (c.nf) {
+            case 8: return launch_nf<AT, CodeT, D, M, 8, 1, true>(a, stream);
+            case 7: return launch_nf<AT, CodeT, D, M, 7, 1, true>(a, stream);
+            case 4: return launch_nf<AT, CodeT, D, M, 4, 1, true>(a, stream);
+            default: break;
+            }
+        }
+        return c.nf == 2 ? launch_nf<AT, CodeT, D, M, 2, 1, true>(a, stream)
+                         : launch_nf<AT, CodeT, D, M, 1, 1, true>(a, stream);
     }
-    switch (choose_nf(a, false)) {
-    case 4: return launch_nf<AT, CodeT, D, M, 4, false>(a, stream);
-    case 2: return launch_nf<AT, CodeT, D, M, 2, false>(a, stream);
-    default: return launch_nf<AT, CodeT, D, M, 1, false>(a, stream);
-    }
+    if constexpr (LIGHT)
+        if (c.nf == 4) return launch_nf<AT, CodeT, D, M, 4, 1, false>(a, stream);
+    return c.nf == 2 ? launch_nf<AT, CodeT, D, M, 2, 1, false>(a, stream)
+                     : launch_nf<AT, CodeT, D, M, 1, 1, false>(a, stream);
 }
 
 template <typename AT>

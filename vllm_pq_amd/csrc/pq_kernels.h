@@ -41,6 +41,10 @@ hipError_t launch_gemm_generic(const GemmArgs &a, hipStream_t stream);
 
 // Fused gather + MFMA, weight-streaming (small T).  supported() says whether the format fits.
 bool gemm_stream_supported(const GemmArgs &a);
+// Tile shape of the streaming kernel for this problem: NF 16-row weight fragments x TF 16-token fragments
+// per block.  *model_us (optional) receives the modelled launch duration for T > 16, 0 otherwise.
+struct StreamCfg { int nf, tf; };
+StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us);
 hipError_t launch_gemm_stream(const GemmArgs &a, hipStream_t stream);
 
 // Load-time re-layout of the codes for the MFMA kernels.
