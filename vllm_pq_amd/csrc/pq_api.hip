@@ -67,14 +67,16 @@ Kernel choose(const pq::GemmArgs &a) {
     const bool ti = pq::gemm_tiled_supported(a);
     if (ti && st && a.T > 16) {
         // Mid-size batches.  The tiled kernel does not split K, so below 256 output tiles of 64 x 64 it
-        // cannot fill the 256 CUs and one launch lasts about 3 us + 4.2 us per 1024 input features (one
-        // 64 x 64 tile per CU, measured); the streaming kernel splits K over its waves and wins there
-        // whenever its own modelled duration is shorter.
+        // cannot fill the 256 CUs and one launch lasts about 3 us + 3 us per 1024 input features (one
+        // 64 x 64 tile per CU, measured: the HBM latency of the code loads paces the short steps); the
+        // streaming kernel splits K over its waves and wins there whenever its own modelled duration is
+        // shorter.
         const double out_tiles = (double)a.T * a.N / 4096.0;
         if (out_tiles <= 256.0) {
             double stream_us = 0.0;
             pq::choose_stream_cfg(a, &stream_us);
-            const double tiled_us = 3.0 + 4.2 * (double)a.G * a.d / 1024.0;
+            const long tiles64 = (long)((a.N + 63) / 64) * ((a.T + 63) / 64);
+            const double tiled_us = (double)((tiles64 + 255) / 256) * (3.0 + 3.0 * (double)a.G * a.d / 1024.0);
             if (stream_us > 0.0 && stream_us <= tiled_us) return K_STREAM;
         }
         return K_TILED;

@@ -52,15 +52,18 @@ static bool stream_light_format(const GemmArgs &a) { return a.d == 8 && a.M == 1
 
 // Duration model of one launch in microseconds, fitted on the MI355X for 17 <= T <= 512: the blocks run
 // in rounds of one per CU; a block costs a fixed 4 us (launch, codebook image, first loads, cross-wave
-// sum) plus 0.95 us per (chunk of one wave) x (accumulator fragment): with more than 16 tokens the
-// activation loads from L2, only one sub-chunk ahead, set the pace, not the code stream.
+// sum) plus 1.9 us per activation sub-load of a wave: with more than 16 tokens the round trips of the
+// activation loads to L2, only one sub-chunk ahead, set the pace, not the code stream or the MFMAs.  A
+// sub-load is 32 registers, i.e. 8 / TF k-steps of the chunk's KS.
 static double stream_model_us(const GemmArgs &a, int nf, int tf) {
     const int cg = chunk_groups(a.code_bytes, a.M);
+    const int ks = (cg / 4) * a.d / 8;                               // k-steps per chunk
     const double nchunks = (double)((a.G + cg - 1) / cg);
     const long blocks = (long)tiles_in(a.parts, nf * 16) * ((a.T + 16 * tf - 1) / (16 * tf));
     const double rounds = (double)((blocks + 255) / 256);
     const double per_wave = nchunks / 8.0 < 1.0 ? 1.0 : nchunks / 8.0;
-    return rounds * (4.0 + per_wave * nf * tf * 0.95);
+    const int subk = 8 / tf < ks ? 8 / tf : ks;
+    return rounds * (4.0 + per_wave * (ks / subk) * 1.9);
 }
 
 StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {

@@ -11,7 +11,9 @@ hipError_t launch_gemm_tiled_fp16(const GemmArgs &a, hipStream_t stream);
 bool gemm_tiled_supported(const GemmArgs &a) {
     if (!a.packed) return false;
     if (!packable(a.parts, a.d, a.K, a.M, a.code_bytes)) return false;
-    // activations are staged in whole 64-feature tiles, codes consumed in register pieces of TPP tiles
+    // activations are staged in whole 64-feature tiles, codes consumed in register pieces of one or two
+    // tiles (the tile shapes with several tiles per ring stage ask for more and are skipped when Kin does
+    // not divide)
     {
         const int ks = ((16 / a.code_bytes) / a.M) * a.d / 8;          // k-steps per code chunk
         const int spp = ks >= 8 ? ks / 4 : ks >= 4 ? ks / 2 : ks;      // k-steps per piece

@@ -6,7 +6,9 @@
 // weight is never staged: it is the MFMA A operand, and lane l's fragment (row l&15, k = 8(l>>4)..+7)
 // is one d=8 centroid (two d=4, four d=2), read with one ds_read_b128 from the replicated LDS
 // codebook image at the address the lane's code selects (see pq_gemm_stream_impl.cuh).  Only the
-// activations go through LDS: a [BT][64] tile per step, written by LDS-DMA into a 3-deep ring, XOR-swizzled so that the
+// activations go through LDS: [BT][64] tiles, written by LDS-DMA into a ring of 3 stages of KT tiles each
+// (32 KiB a stage whatever the tile shape: small token tiles take more k per stage, so that as many
+// bytes are in flight and a barrier is as rare as with the large ones), XOR-swizzled so that the
 // B-operand reads (16 tokens x 4 k-octets per wave-instruction) are bank-conflict free.  A gathered
 // A fragment is reused for WT token fragments, an activation fragment for WN weight fragments.
 //
@@ -38,11 +40,11 @@ __device__ inline uint32_t xt_off(int row, int slot) { return (uint32_t)row * 12
 // tokens.
 // ABL (diagnostic builds only; 0 in the library): bit 0 skips the LDS store of the next tile and the
 // barrier, bit 1 the activation loads, bit 2 the epilogue stores, bit 3 the gathers.
-template <typename AT, typename CodeT, int D, int M, int WAVES_T, int WN, int WT, int ABL = 0>
+template <typename AT, typename CodeT, int D, int M, int WAVES_T, int WN, int WT, int KT, int ABL = 0>
 __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     const uint16_t *__restrict__ x, int T, int64_t x_stride, const u32x4 *__restrict__ packed,
     const uint16_t *__restrict__ codebooks, const uint16_t *__restrict__ scales, const uint16_t *__restrict__ bias,
-    Parts parts, int G, int K, int nbits, int R, uint16_t *__restrict__ y, int64_t y_stride, int n_tiles,
+    TileMap tmap, int G, int K, int nbits, int R, uint16_t *__restrict__ y, int64_t y_stride, int n_tiles,
     int t_tiles) {
     typedef typename Act<AT>::vec8 vec8;
     typedef StreamFmt<sizeof(CodeT), D, M> F;
@@ -53,16 +55,21 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     constexpr int BN = WAVES_N * WN * 16;            // weight rows per block
     constexpr int BT = WAVES_T * WT * 16;            // tokens per block
     constexpr int XT_BYTES = BT * TL_BK * 2;         // one activation tile
-    constexpr int NBUF = 3;                          // LDS buffers: one being read, two in flight
+    constexpr int STAGE_BYTES = KT * XT_BYTES;       // one ring stage: KT consecutive tiles
+    constexpr int NBUF = 3;                          // ring stages: one being read, two in flight
     constexpr int PPW = BT / 64;                     // one-KiB pieces per wave per tile
     // The codes of a chunk are consumed in PIECES register pieces (a half or a quarter of a lane's 16
-    // bytes), so that the next piece can be prefetched with few live registers.
+    // bytes), so that the next ones can be prefetched with few live registers.
     constexpr int SPP = KS >= 8 ? KS / 4 : KS >= 4 ? KS / 2 : KS;   // k-steps per code piece
     constexpr int PIECES = KS / SPP;                 // pieces per chunk: 1, 2 or 4
     constexpr int PW = 4 / PIECES;                   // dwords per piece
     constexpr int TPP = SPP / 2;                     // 64-k tiles per piece
+    // The main loop advances by U tiles: whole pieces and whole ring stages.
+    constexpr int U = KT > TPP ? KT : TPP;
+    constexpr int PPU = U / TPP;                     // pieces per loop step
+    constexpr int SPU = U / KT;                      // ring stages per loop step
     typedef uint32_t piece_t __attribute__((ext_vector_type(PW)));
-    static_assert(KS % 2 == 0, "a code chunk must cover whole 64-k tiles");
+    static_assert(KS % 2 == 0 && U % TPP == 0 && U % KT == 0, "pieces and stages must tile the loop step");
     static_assert(PPW >= 1, "tile too small for the block");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     const int pair = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (pair >= total) return;
     const int t_tile = pair / n_tiles;
-    const TileLoc loc = locate_tile(parts, pair - t_tile * n_tiles, BN);
+    const TileLoc loc = locate_tile(tmap, pair - t_tile * n_tiles, BN);
     const int t0 = t_tile * BT;
     const int row_end = loc.row0 + loc.nrows;
     const int Kin = G * D;
@@ -95,8 +102,9 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     // linearly (LDS address = piece base + lane*16), so the XOR swizzle goes on the per-lane SOURCE: LDS
     // slot l%8 of row l/8 receives logical 16-byte slot (l%8) ^ (l/8) of that row.  Tokens past T read the
     // last valid row (their outputs are never stored).
-    const int ntiles_k = Kin / TL_BK;                // Kin % (64*TPP) == 0, checked on the host
-    const int npieces = ntiles_k / TPP;
+    const int ntiles_k = Kin / TL_BK;                // Kin % (64*U) == 0, checked on the host
+    const int nstages = ntiles_k / KT;
+    const int nsteps = ntiles_k / U;
     const unsigned char *xbase = reinterpret_cast<const unsigned char *>(x + (size_t)t0 * x_stride);
     uint32_t goff[PPW];
 #pragma unroll
@@ -105,18 +113,76 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
         row = t0 + row < T ? row : T - 1 - t0;
         goff[j] = (uint32_t)row * (uint32_t)(x_stride * 2) + (uint32_t)(((lane & 7) ^ (lane >> 3)) << 4);
     }
-    auto x_issue = [&](int kt, int buf) {            // tile kt -> buffer buf (both wave-uniform)
+    auto x_issue = [&](int st, int buf) {            // stage st -> ring slot buf (both wave-uniform)
         if constexpr (ABL & 2) return;
-        const uint32_t kb = (uint32_t)(kt < ntiles_k ? kt : ntiles_k - 1) * (TL_BK * 2);
-        unsigned char *dst = xt + buf * XT_BYTES + wave * (PPW * 1024);
+        // a stage past the end re-reads the last one (nobody reads that slot again): no branch around a load
+        const uint32_t kb = (uint32_t)(st < nstages ? st : nstages - 1) * (KT * TL_BK * 2);
+        unsigned char *dst = xt + buf * STAGE_BYTES + wave * (PPW * 1024);
 #pragma unroll
-        for (int j = 0; j < PPW; ++j)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(xbase + (goff[j] + kb)),
-                (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int j = 0; j < PPW; ++j)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(xbase + (goff[j] + kb + it * (TL_BK * 2))),
+                    (__attribute__((address_space(3))) void *)(dst + it * XT_BYTES + j * 1024), 16, 0, 0);
     };
     x_issue(0, 0);
     x_issue(1, 1);
+
+    // fragment bases are wave-uniform (scalar registers); the per-lane part is one 32-bit offset
+    const unsigned char *fbase[WN];
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+        const int fi = wn * WN + i;
+        const int f = f0 + (fi < nfr ? fi : nfr - 1);
+        fbase[i] = reinterpret_cast<const unsigned char *>(packed) + (size_t)f * nchunks * 1024;
+    }
+    // The PPU code pieces of loop step u, requested with inline-asm loads: the compiler neither moves
+    // them across the DMA issue nor waits for them on its own (it drains vmcnt to 0 for any tracked load
+    // that is pending together with an LDS-DMA), so the counted waits below are exact.  Until `landed`
+    // has been applied to a set after such a wait, its registers must not be read.
+    auto load_pieces = [&](piece_t (&dst)[PPU][WN], int u) {
+#pragma unroll
+        for (int pi = 0; pi < PPU; ++pi) {
+            const int p = u * PPU + pi;
+            const uint32_t off =
+                (uint32_t)(p / PIECES) * 1024u + (uint32_t)lane * 16u + (uint32_t)(p % PIECES) * (16u / PIECES);
+#pragma unroll
+            for (int i = 0; i < WN; ++i) {
+#pragma unroll
+                for (int w = 0; w < PW; ++w) {
+                    uint32_t t;
+                    if (w == 0) asm volatile("global_load_dword %0, %1, %2" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
+                    else if (w == 1) asm volatile("global_load_dword %0, %1, %2 offset:4" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
+                    else if (w == 2) asm volatile("global_load_dword %0, %1, %2 offset:8" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
+                    else asm volatile("global_load_dword %0, %1, %2 offset:12" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
+                    dst[pi][i][w] = t;
+                }
+            }
+        }
+    };
+    constexpr int CL = PPU * WN * PW;                // code loads per loop step
+    constexpr bool DEEP = KT > 1 && CL <= 8;         // prefetch codes two steps ahead (three register sets)
+    static_assert(!DEEP || SPU == 1, "deep code prefetch assumes one stage per step");
+    // makes every later read of the set depend on this point in the instruction stream
+    auto landed = [&](piece_t (&c)[PPU][WN]) {
+#pragma unroll
+        for (int pi = 0; pi < PPU; ++pi) {
+#pragma unroll
+            for (int i = 0; i < WN; ++i) {
+#pragma unroll
+                for (int w = 0; w < PW; ++w) {
+                    uint32_t t = c[pi][i][w];
+                    asm volatile("" : "+v"(t));
+                    c[pi][i][w] = t;
+                }
+            }
+        }
+    };
+    // the codes of the first two steps travel while the codebook image is built
+    piece_t c0[PPU][WN], c1[PPU][WN], c2[PPU][WN];
+    load_pieces(c0, 0);
+    load_pieces(c1, nsteps > 1 ? 1 : 0);
 
     // ---- codebook image ---------------------------------------------------------------------------
     {
@@ -137,88 +203,104 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
 
     // everything issued so far (two tiles, the image) has landed before the first read
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landed(c0);
+    landed(c1);
     __syncthreads();
 
-    // fragment bases are wave-uniform (scalar registers); the per-lane part is one 32-bit offset
-    const unsigned char *fbase[WN];
-#pragma unroll
-    for (int i = 0; i < WN; ++i) {
-        const int fi = wn * WN + i;
-        const int f = f0 + (fi < nfr ? fi : nfr - 1);
-        fbase[i] = reinterpret_cast<const unsigned char *>(packed) + (size_t)f * nchunks * 1024;
-    }
-    auto load_piece = [&](piece_t (&dst)[WN], int p) {
-        const uint32_t off = (uint32_t)(p / PIECES) * 1024u + (uint32_t)lane * 16u + (uint32_t)(p % PIECES) * (16u / PIECES);
-#pragma unroll
-        for (int i = 0; i < WN; ++i) dst[i] = *reinterpret_cast<const piece_t *>(fbase[i] + off);
-    };
-    // Per tile: issue the DMA of tile kt+2, compute tile kt, wait until only those newest PPW DMAs are
-    // outstanding (tile kt+1 has landed for this wave), barrier (landed for every wave; and everybody
-    // is done reading tile kt, whose buffer the next iteration's DMA overwrites).  No branch around a
-    // load and no __syncthreads() in the loop: either would drain vmcnt and stall the DMA pipeline.
-    piece_t cw[WN], cwn[WN];
-    load_piece(cw, 0);
-    // consume the first piece's registers here, so that the compiler waits for these loads before the
-    // loop and not (with vmcnt(0), draining the DMA just issued) at the loop head
-#pragma unroll
-    for (int i = 0; i < WN; ++i) {
-#pragma unroll
-        for (int w = 0; w < PW; ++w) {
-            uint32_t t = cw[i][w];
-            asm volatile("" : "+v"(t));
-            cw[i][w] = t;
-        }
-    }
+    // Loop step u of U tiles: request the codes of a later step, then per ring stage: issue the DMA of
+    // stage st+2, compute stage st, wait until only what was issued after the DMA of stage st+1 is
+    // outstanding (that stage has landed for this wave), barrier (landed for every wave; and everybody is
+    // done reading stage st, whose slot the next DMA overwrites).  No branch around a load and no
+    // __syncthreads() in the loop: either would drain vmcnt and stall the DMA pipeline.
+    //   DEEP (several tiles per stage, small code sets): three code sets; step u requests the codes of step
+    //     u+2, which are older than everything step u+1 issues and so have landed after the wait of step u+1;
+    //   otherwise two sets: step u requests the codes of step u+1, which are older than the DMA issued in the
+    //     step's last stage and so have landed after the step's last wait.
     int buf = 0, buf2 = 2;
-    for (int p = 0; p < npieces; ++p) {
-        load_piece(cwn, p + 1 < npieces ? p + 1 : p);  // older than this piece's DMAs: landed by the first wait
+    auto step = [&](const piece_t (&cur)[PPU][WN], piece_t (&lands)[PPU][WN], piece_t (&req)[PPU][WN], int u) {
+        constexpr int AHEAD = DEEP ? 2 : 1;
+        load_pieces(req, u + AHEAD < nsteps ? u + AHEAD : nsteps - 1);
 #pragma unroll
-        for (int it = 0; it < TPP; ++it) {
-            const int kt = p * TPP + it;
-            x_issue(kt + 2, buf2);
-            const unsigned char *xb = xt + buf * XT_BYTES;
+        for (int sg = 0; sg < SPU; ++sg) {
+            x_issue(u * SPU + sg + 2, buf2);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int s = it * 2 + ks;             // k-step within the piece (compile-time)
-                vec8 xf[WT];
+            for (int it = 0; it < KT; ++it) {
+                const int tt = sg * KT + it;           // tile within the loop step (compile-time)
+                const unsigned char *xb = xt + buf * STAGE_BYTES + it * XT_BYTES;
 #pragma unroll
-                for (int j = 0; j < WT; ++j) {
-                    const int row = (wt * WT + j) * 16 + r16;
-                    xf[j] = *reinterpret_cast<const vec8 *>(xb + xt_off(row, ks * 4 + q));
-                }
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int s = (tt % TPP) * 2 + ks; // k-step within the piece
+                    vec8 xf[WT];
 #pragma unroll
-                for (int i = 0; i < WN; ++i) {
-                    vec8 a;
-#pragma unroll
-                    for (int m = 0; m < M; ++m) {
-                        uint32_t idx[CPS];
-#pragma unroll
-                        for (int u = 0; u < CPS; ++u)
-                            idx[u] = code_at<CB>(cw[i], (s * CPS + u) * M + m, (uint32_t)nbits);
-                        vec8 am;
-                        if constexpr (ABL & 8) {
-                            const u32x4 fake{idx[0], idx[0] + 1, idx[0] ^ 5, idx[0] * 3};
-                            am = __builtin_bit_cast(vec8, fake);
-                        } else {
-                            am = gather_frag<AT, D>(smem + m * cb_stride, idx, shift, lane_off);
-                        }
-                        a = m == 0 ? am : Act<AT>::add8(a, am);
+                    for (int j = 0; j < WT; ++j) {
+                        const int row = (wt * WT + j) * 16 + r16;
+                        xf[j] = *reinterpret_cast<const vec8 *>(xb + xt_off(row, ks * 4 + q));
                     }
 #pragma unroll
-                    for (int j = 0; j < WT; ++j) acc[i][j] = Act<AT>::mfma16(a, xf[j], acc[i][j]);
+                    for (int i = 0; i < WN; ++i) {
+                        vec8 a;
+#pragma unroll
+                        for (int m = 0; m < M; ++m) {
+                            uint32_t idx[CPS];
+#pragma unroll
+                            for (int c = 0; c < CPS; ++c)
+                                idx[c] = code_at<CB>(cur[tt / TPP][i], (s * CPS + c) * M + m, (uint32_t)nbits);
+                            vec8 am;
+                            if constexpr (ABL & 8) {
+                                const u32x4 fake{idx[0], idx[0] + 1, idx[0] ^ 5, idx[0] * 3};
+                                am = __builtin_bit_cast(vec8, fake);
+                            } else {
+                                am = gather_frag<AT, D>(smem + m * cb_stride, idx, shift, lane_off);
+                            }
+                            a = m == 0 ? am : Act<AT>::add8(a, am);
+                        }
+#pragma unroll
+                        for (int j = 0; j < WT; ++j) acc[i][j] = Act<AT>::mfma16(a, xf[j], acc[i][j]);
+                    }
                 }
             }
             if constexpr (!(ABL & 1)) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+                // younger than the DMA of stage st+1: this stage's DMA and, in a step's first stage, its code loads
+                if (sg == 0 && (DEEP || SPU > 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KT * PPW + CL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KT * PPW) : "memory");
+                if (sg == SPU - 1) landed(lands);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+            } else {
+                if (sg == SPU - 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    landed(lands);
+                }
             }
             buf = buf == NBUF - 1 ? 0 : buf + 1;
             buf2 = buf2 == NBUF - 1 ? 0 : buf2 + 1;
         }
-#pragma unroll
-        for (int i = 0; i < WN; ++i) cw[i] = cwn[i];
+    };
+    if constexpr (DEEP) {
+        int u = 0;
+        for (; u + 3 <= nsteps; u += 3) {
+            step(c0, c1, c2, u);
+            step(c1, c2, c0, u + 1);
+            step(c2, c0, c1, u + 2);
+        }
+        if (u < nsteps) {
+            step(c0, c1, c2, u);
+            if (u + 1 < nsteps) step(c1, c2, c0, u + 1);
+        }
+    } else {
+        int u = 0;
+        for (; u + 2 <= nsteps; u += 2) {
+            step(c0, c1, c1, u);
+            step(c1, c0, c0, u + 1);
+        }
+        if (u < nsteps) step(c0, c1, c1, u);
     }
+    // The last steps requested codes nobody reads: keep their registers reserved until those loads have
+    // returned, or a late return would overwrite whatever the epilogue keeps there.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landed(c0);
+    landed(c1);
+    if constexpr (DEEP) landed(c2);
 
     // ---- epilogue: scale, bias, round, store (lane holds 4 consecutive rows of one token) --------
 #pragma unroll
@@ -259,7 +341,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
 }
 
 // ---- per-dtype launcher ---------------------------------------------------------------------------
-template <typename AT, typename CodeT, int D, int M, int WAVES_T, int WN, int WT>
+template <typename AT, typename CodeT, int D, int M, int WAVES_T, int WN, int WT, int KT>
 static hipError_t tiled_launch_cfg(const GemmArgs &a, hipStream_t stream) {
     constexpr int BN = (TL_WAVES / WAVES_T) * WN * 16;
     constexpr int BT = WAVES_T * WT * 16;
@@ -269,8 +351,8 @@ static hipError_t tiled_launch_cfg(const GemmArgs &a, hipStream_t stream) {
     const int t_tiles = (a.T + BT - 1) / BT;
     const int total = n_tiles * t_tiles;
     const int per_xcd = (total + 7) / 8;
-    const size_t lds = (size_t)ST_MAX_LDS_CB + 3 * (size_t)BT * TL_BK * 2;
-    auto kern = gemm_tiled_kernel<AT, CodeT, D, M, WAVES_T, WN, WT>;
+    const size_t lds = (size_t)ST_MAX_LDS_CB + 3 * (size_t)KT * BT * TL_BK * 2;
+    auto kern = gemm_tiled_kernel<AT, CodeT, D, M, WAVES_T, WN, WT, KT>;
     static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -280,29 +362,46 @@ static hipError_t tiled_launch_cfg(const GemmArgs &a, hipStream_t stream) {
     }
     hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(TL_THREADS), lds, stream, static_cast<const uint16_t *>(a.x), a.T,
                        a.x_stride, static_cast<const u32x4 *>(a.codes), static_cast<const uint16_t *>(a.codebooks),
-                       static_cast<const uint16_t *>(a.scales), static_cast<const uint16_t *>(a.bias), a.parts, a.G,
-                       a.K, nbits, R, static_cast<uint16_t *>(a.y), a.y_stride, n_tiles, t_tiles);
+                       static_cast<const uint16_t *>(a.scales), static_cast<const uint16_t *>(a.bias),
+                       make_tile_map(a.parts, BN), a.G, a.K, nbits, R, static_cast<uint16_t *>(a.y), a.y_stride, n_tiles,
+                       t_tiles);
     return hipGetLastError();
 }
 
 // Tile shapes, largest first: {rows, tokens}.  Bigger tiles reuse each gathered weight fragment and
 // each activation fragment more often; smaller ones give the 256 CUs enough blocks.
-struct TiledCfg { int bn, bt; };
-static const TiledCfg kTiledCfgs[] = {{256, 256}, {256, 128}, {128, 128}, {256, 64}, {128, 64}, {64, 64}};
+// kt = 64-k tiles per ring stage (256 / bt: every shape keeps 32 KiB a stage); Kin must be a multiple of 64 kt.
+struct TiledCfg { int bn, bt, kt; };
+static const TiledCfg kTiledCfgs[] = {{256, 256, 1}, {256, 128, 2}, {128, 128, 2}, {256, 64, 4}, {128, 64, 4}, {64, 64, 4}};
 constexpr int kNumTiledCfgs = 6;
+
+// 64-k tiles per main-loop step of a shape with kt tiles per ring stage: whole stages and whole code pieces
+static int tiled_step_tiles(const GemmArgs &a, int kt) {
+    const int ks = ((16 / a.code_bytes) / a.M) * a.d / 8;             // k-steps per code chunk
+    const int tpp = (ks >= 8 ? ks / 4 : ks >= 4 ? ks / 2 : ks) / 2;  // tiles per code piece
+    return kt > tpp ? kt : tpp;
+}
+
+// Shape i for this format.  With d = 2 a lane holds four times the codes per k-step, and the 256 x 256
+// shape would not fit the register file: its slot is a 256 x 128 tile with one k-tile per stage.
+static TiledCfg tiled_cfg(const GemmArgs &a, int i) {
+    if (i == 0 && a.d == 2) return TiledCfg{256, 128, 1};
+    return kTiledCfgs[i];
+}
 
 static int choose_tiled_cfg(const GemmArgs &a) {
     const char *env = getenv("PQ_AMD_TILED_CFG");
     if (env && *env) {
         const int v = atoi(env);
-        if (v >= 0 && v < kNumTiledCfgs) return v;
+        if (v >= 0 && v < kNumTiledCfgs && (a.G * a.d) % (64 * tiled_step_tiles(a, tiled_cfg(a, v).kt)) == 0) return v;
     }
     // Token tile: do not pad T by more than it has to be; then the largest row tile that still yields
     // about one block per CU, else the shape with the most blocks.
-    int best = kNumTiledCfgs - 1;
+    int best = 0;   // shape 0 takes any Kin the kernel supports
     long best_blocks = -1;
     for (int i = 0; i < kNumTiledCfgs; ++i) {
-        const TiledCfg &c = kTiledCfgs[i];
+        const TiledCfg c = tiled_cfg(a, i);
+        if ((a.G * a.d) % (64 * tiled_step_tiles(a, c.kt))) continue;
         if (c.bt > 64 && a.T <= c.bt / 2) continue;                 // more than half the tile would be padding
         const long blocks = (long)tiles_in(a.parts, c.bn) * ((a.T + c.bt - 1) / c.bt);
         if (blocks >= 200) return i;
@@ -314,12 +413,14 @@ static int choose_tiled_cfg(const GemmArgs &a) {
 template <typename AT, typename CodeT, int D, int M>
 static hipError_t tiled_launch_fmt(const GemmArgs &a, hipStream_t stream) {
     switch (choose_tiled_cfg(a)) {
-    case 0: return tiled_launch_cfg<AT, CodeT, D, M, 4, 8, 4>(a, stream);   // 256 x 256
-    case 1: return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4>(a, stream);   // 256 x 128
-    case 2: return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 4>(a, stream);   // 128 x 128
-    case 3: return tiled_launch_cfg<AT, CodeT, D, M, 1, 2, 4>(a, stream);   // 256 x 64
-    case 4: return tiled_launch_cfg<AT, CodeT, D, M, 1, 1, 4>(a, stream);   // 128 x 64
-    default: return tiled_launch_cfg<AT, CodeT, D, M, 2, 1, 2>(a, stream);  //  64 x 64
+    case 0:
+        if constexpr (D == 2) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 1>(a, stream);   // 256 x 128
+        else return tiled_launch_cfg<AT, CodeT, D, M, 4, 8, 4, 1>(a, stream);                    // 256 x 256
+    case 1: return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 2>(a, stream);   // 256 x 128
+    case 2: return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 4, 2>(a, stream);   // 128 x 128
+    case 3: return tiled_launch_cfg<AT, CodeT, D, M, 1, 2, 4, 4>(a, stream);   // 256 x 64
+    case 4: return tiled_launch_cfg<AT, CodeT, D, M, 1, 1, 4, 4>(a, stream);   // 128 x 64
+    default: return tiled_launch_cfg<AT, CodeT, D, M, 2, 1, 2, 4>(a, stream);  //  64 x 64
     }
 }
 
