@@ -244,6 +244,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--layers", type=int, default=None, help="decoder layers (default: all 32)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--graph-collectives", action="store_true",
+                    help="with --gpus > 1, also capture the steps (RCCL all-reduces included) into a HIP graph; "
+                         "by default multi-GPU steps are launched eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     args = ap.parse_args()
@@ -273,7 +276,9 @@ def main():
     from vllm_pq_amd import ops
     stack = build_stack(world, device, dtype, layers=args.layers)
     T = args.tokens
-    use_graph = not args.no_graph
+    # a step with collectives is launched eagerly unless asked otherwise: the launches are asynchronous and
+    # hide behind the GPU work at the default token count, and no capture of RCCL calls can fail the run
+    use_graph = not args.no_graph and (world == 1 or args.graph_collectives)
 
     main_m = measure(stack, T, args.steps, args.warmup, device, dtype, world, dist_on, use_graph)
 

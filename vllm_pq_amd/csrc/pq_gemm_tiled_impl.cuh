@@ -409,12 +409,13 @@ static hipError_t tiled_launch_cfg(const GemmArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// Tile shapes, largest first: {rows, tokens}.  Bigger tiles reuse each gathered weight fragment and
+// Tile shapes: {rows, tokens}.  Bigger tiles reuse each gathered weight fragment and
 // each activation fragment more often; smaller ones give the 256 CUs enough blocks.
 // kt = 64-k tiles per ring stage (256 / bt: every shape keeps 32 KiB a stage); Kin must be a multiple of 64 kt.
 struct TiledCfg { int bn, bt, kt; };
-static const TiledCfg kTiledCfgs[] = {{256, 256, 1}, {256, 128, 2}, {128, 128, 2}, {256, 64, 4}, {128, 64, 4}, {64, 64, 4}};
-constexpr int kNumTiledCfgs = 6;
+static const TiledCfg kTiledCfgs[] = {{256, 256, 1}, {256, 128, 2}, {128, 128, 2}, {256, 64, 4}, {128, 64, 4}, {64, 64, 4},
+                                      {512, 128, 2}};
+constexpr int kNumTiledCfgs = 7;
 
 // 64-k tiles per main-loop step of a shape with kt tiles per ring stage: whole stages and whole code pieces
 static int tiled_step_tiles(const GemmArgs &a, int kt) {
@@ -427,6 +428,8 @@ static int tiled_step_tiles(const GemmArgs &a, int kt) {
 // shape would not fit the register file: its slot is a 256 x 128 tile with one k-tile per stage.
 static TiledCfg tiled_cfg(const GemmArgs &a, int i) {
     if (i == 0 && a.d == 2) return TiledCfg{256, 128, 1};
+    // the 512 x 128 shape exists for d = 8, one codebook, one-byte codes; other formats run 256 x 128 in its slot
+    if (i == 6 && !(a.d == 8 && a.M == 1 && a.code_bytes == 1)) return kTiledCfgs[1];
     return kTiledCfgs[i];
 }
 
@@ -440,7 +443,10 @@ static int choose_tiled_cfg(const GemmArgs &a) {
     // about one block per CU, else the shape with the most blocks.
     int best = 0;   // shape 0 takes any Kin the kernel supports
     long best_blocks = -1;
-    for (int i = 0; i < kNumTiledCfgs; ++i) {
+    // order of preference: 512 x 128 first (same work per wave as 256 x 256, half the DMA instructions and
+    // barriers per k), then by decreasing tile area
+    static const int order[kNumTiledCfgs] = {6, 0, 1, 2, 3, 4, 5};
+    for (int i : order) {
         const TiledCfg c = tiled_cfg(a, i);
         if ((a.G * a.d) % (64 * tiled_step_tiles(a, c.kt))) continue;
         if (c.bt > 64 && a.T <= c.bt / 2) continue;                 // more than half the tile would be padding
@@ -461,6 +467,9 @@ static hipError_t tiled_launch_fmt(const GemmArgs &a, hipStream_t stream) {
     case 2: return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 4, 2>(a, stream);   // 128 x 128
     case 3: return tiled_launch_cfg<AT, CodeT, D, M, 1, 2, 4, 4>(a, stream);   // 256 x 64
     case 4: return tiled_launch_cfg<AT, CodeT, D, M, 1, 1, 4, 4>(a, stream);   // 128 x 64
+    case 6:
+        if constexpr (D == 8 && M == 1 && sizeof(CodeT) == 1) return tiled_launch_cfg<AT, CodeT, D, M, 2, 8, 4, 2>(a, stream);   // 512 x 128
+        else return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 2>(a, stream);
     default: return tiled_launch_cfg<AT, CodeT, D, M, 2, 1, 2, 4>(a, stream);  //  64 x 64
     }
 }
