@@ -439,20 +439,21 @@ static int choose_tiled_cfg(const GemmArgs &a) {
         const int v = atoi(env);
         if (v >= 0 && v < kNumTiledCfgs && (a.G * a.d) % (64 * tiled_step_tiles(a, tiled_cfg(a, v).kt)) == 0) return v;
     }
-    // Token tile: do not pad T by more than it has to be; then the largest row tile that still yields
-    // about one block per CU, else the shape with the most blocks.
-    int best = 0;   // shape 0 takes any Kin the kernel supports
-    long best_blocks = -1;
-    // order of preference: 512 x 128 first (same work per wave as 256 x 256, half the DMA instructions and
-    // barriers per k), then by decreasing tile area
+    // Shortest modelled launch: the blocks run in rounds of one per CU (every shape takes the whole LDS), a
+    // block costs its tile area over the shape's measured throughput (PFLOP/s on a chip-filling problem:
+    // bigger tiles reuse each gathered weight fragment and each activation fragment more often).  Padding
+    // and half-filled last rounds are paid in full; ties go to the larger tile.
+    static const double speed[kNumTiledCfgs] = {1.33, 1.29, 1.085, 1.13, 0.856, 0.622, 1.355};
     static const int order[kNumTiledCfgs] = {6, 0, 1, 2, 3, 4, 5};
+    int best = 0;   // shape 0 takes any Kin the kernel supports
+    double best_cost = -1.0;
     for (int i : order) {
         const TiledCfg c = tiled_cfg(a, i);
         if ((a.G * a.d) % (64 * tiled_step_tiles(a, c.kt))) continue;
-        if (c.bt > 64 && a.T <= c.bt / 2) continue;                 // more than half the tile would be padding
         const long blocks = (long)tiles_in(a.parts, c.bn) * ((a.T + c.bt - 1) / c.bt);
-        if (blocks >= 200) return i;
-        if (blocks > best_blocks) { best_blocks = blocks; best = i; }
+        const double sp = (c.bn == kTiledCfgs[i].bn && c.bt == kTiledCfgs[i].bt) ? speed[i] : speed[1];
+        const double cost = (double)((blocks + 255) / 256) * c.bn * c.bt / sp;
+        if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = i; }
     }
     return best;
 }
