@@ -9,7 +9,7 @@
 using namespace pq;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int WAVES_T, int WN, int WT, int ABL>
+template <int WAVES_T, int WN, int WT, int KT, int ABL>
 float run(const char *label, int T, int N, int G, int nparts) {
     const int K = 256, D = 8, M = 1;
     constexpr int BN = (TL_WAVES / WAVES_T) * WN * 16, BT = WAVES_T * WT * 16;
@@ -40,15 +40,15 @@ float run(const char *label, int T, int N, int G, int nparts) {
     const int R = stream_replication<D>(K, M);
     const int n_tiles = tiles_in(parts, BN), t_tiles = (T + BT - 1) / BT;
     const int per_xcd = (n_tiles * t_tiles + 7) / 8;
-    const size_t lds = (size_t)ST_MAX_LDS_CB + 3 * (size_t)BT * TL_BK * 2;
-    auto kern = gemm_tiled_kernel<bf16_t, int8_t, D, M, WAVES_T, WN, WT, ABL>;
+    const size_t lds = (size_t)ST_MAX_LDS_CB + 3 * (size_t)KT * BT * TL_BK * 2;
+    auto kern = gemm_tiled_kernel<bf16_t, int8_t, D, M, WAVES_T, WN, WT, KT, ABL>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto launch = [&]() {
         hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(TL_THREADS), lds, 0, (const uint16_t *)x, T, (int64_t)G * D,
                            (const u32x4 *)pk, (const uint16_t *)cb, (const uint16_t *)sc, (const uint16_t *)nullptr,
-                           parts, G, K, 8, R, (uint16_t *)y, (int64_t)N, n_tiles, t_tiles);
+                           make_tile_map(parts, BN), G, K, 8, R, (uint16_t *)y, (int64_t)N, n_tiles, t_tiles);
     };
     for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());
@@ -68,16 +68,16 @@ float run(const char *label, int T, int N, int G, int nparts) {
 
 int main(int argc, char **argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 4096;
-    printf("== gate_up 28672 x 4096, 256x256 tile ==\n");
-    run<4, 8, 4, 0>("full", T, 28672, 512, 2);
-    run<4, 8, 4, 1>("no x_store / barrier", T, 28672, 512, 2);
-    run<4, 8, 4, 2>("no x global loads", T, 28672, 512, 2);
-    run<4, 8, 4, 3>("no x loads, store, barrier", T, 28672, 512, 2);
-    run<4, 8, 4, 4>("no epilogue stores", T, 28672, 512, 2);
-    run<4, 8, 4, 8>("no gathers", T, 28672, 512, 2);
-    run<4, 8, 4, 15>("mfma + x frag reads only", T, 28672, 512, 2);
-    printf("== 256x128 tile ==\n");
-    run<2, 4, 4, 0>("full", T, 28672, 512, 2);
-    run<2, 4, 4, 3>("no x loads, store, barrier", T, 28672, 512, 2);
+    printf("== gate_up 28672 x 4096, 512x128 tile ==\n");
+    run<2, 8, 4, 2, 0>("full", T, 28672, 512, 2);
+    run<2, 8, 4, 2, 1>("no wait / barrier", T, 28672, 512, 2);
+    run<2, 8, 4, 2, 2>("no x DMA", T, 28672, 512, 2);
+    run<2, 8, 4, 2, 3>("no x DMA, wait, barrier", T, 28672, 512, 2);
+    run<2, 8, 4, 2, 4>("no epilogue stores", T, 28672, 512, 2);
+    run<2, 8, 4, 2, 8>("no gathers", T, 28672, 512, 2);
+    run<2, 8, 4, 2, 16>("no x fragment reads", T, 28672, 512, 2);
+    run<2, 8, 4, 2, 24>("no gathers, no x fragment reads", T, 28672, 512, 2);
+    run<2, 8, 4, 2, 15>("mfma + x frag reads only", T, 28672, 512, 2);
+    run<2, 8, 4, 2, 31>("mfma only", T, 28672, 512, 2);
     return 0;
 }

@@ -21,12 +21,35 @@
 #pragma once
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "pq_common.cuh"
 #include "pq_gather.cuh"
 #include "pq_kernels.h"
 #include "pq_stream_geom.cuh"
 
 namespace pq {
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// ds_read_b128 by inline asm: the compiler does not track it, so the counted s_waitcnt lgkmcnt(n) placed by
+// hand below are what is executed (its own waits for LDS reads are always lgkmcnt(0)).  OFF is the
+// instruction's immediate byte offset.
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
 
 constexpr int TL_THREADS = 512;
 constexpr int TL_WAVES = 8;
@@ -39,7 +62,8 @@ __device__ inline uint32_t xt_off(int row, int slot) { return (uint32_t)row * 12
 // fragments x WT token fragments, so the block tile is (8/WAVES_T * WN * 16) rows x (WAVES_T * WT * 16)
 // tokens.
 // ABL (diagnostic builds only; 0 in the library): bit 0 skips the LDS store of the next tile and the
-// barrier, bit 1 the activation loads, bit 2 the epilogue stores, bit 3 the gathers.
+// barrier, bit 1 the activation loads, bit 2 the epilogue stores, bit 3 the gathers, bit 4 the activation
+// fragment reads from LDS.
 template <typename AT, typename CodeT, int D, int M, int WAVES_T, int WN, int WT, int KT, int ABL = 0>
 __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     const uint16_t *__restrict__ x, int T, int64_t x_stride, const u32x4 *__restrict__ packed,
@@ -69,6 +93,8 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     constexpr int PPU = U / TPP;                     // pieces per loop step
     constexpr int SPU = U / KT;                      // ring stages per loop step
     typedef uint32_t piece_t __attribute__((ext_vector_type(PW)));
+    // hand-pipelined LDS reads in the main loop: d = 8, one codebook, fragments taken in pairs
+    constexpr bool PIPE = D == 8 && M == 1 && WN % 2 == 0 && WT % 2 == 0 && !(ABL & (8 | 16));
     static_assert(KS % 2 == 0 && U % TPP == 0 && U % KT == 0, "pieces and stages must tile the loop step");
     static_assert(PPW >= 1, "tile too small for the block");
 
@@ -200,6 +226,14 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     const uint32_t shift = (uint32_t)__builtin_ctz((unsigned)(EB * R));
     const uint32_t lane_off = (uint32_t)(lane & (R - 1)) * EB;
     const uint32_t cb_stride = (uint32_t)K * EB * R;
+    // LDS byte addresses for the hand-issued reads: this lane's copy of codebook entry 0, and its slot of
+    // activation-tile row (first token fragment of the wave) for the two k-steps of a tile
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const uint32_t img_lane = lds_base + lane_off;
+    uint32_t xlane[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        xlane[ks] = lds_base + ST_MAX_LDS_CB + xt_off(wt * WT * 16 + r16, ks * 4 + q);
 
     // everything issued so far (two tiles, the image) has landed before the first read
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -223,6 +257,80 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
 #pragma unroll
         for (int sg = 0; sg < SPU; ++sg) {
             x_issue(u * SPU + sg + 2, buf2);
+            if constexpr (PIPE) {
+                // One stage = NKS k-steps x NPAIR fragment pairs = NG groups of 2 gathers + 2*WT MFMAs, software-
+                // pipelined by hand: the gathers of group g+1 are issued before the MFMAs of group g, and the
+                // activation fragments of the next k-step are re-read right behind their last use in the last
+                // group of a k-step.  LDS reads return in order, so `lgkmcnt(n)` = all but the n newest.
+                constexpr int NKS = KT * 2, NPAIR = WN / 2, NG = NKS * NPAIR, H = WT / 2;
+                const uint32_t xs0 = xlane[0] + (uint32_t)buf * STAGE_BYTES, xs1 = xlane[1] + (uint32_t)buf * STAGE_BYTES;
+                u32x4 xfr[WT], P[2][2];
+                auto gather_pair = [&](auto gc, u32x4 (&dst)[2]) {        // group gc -> its two weight fragments
+                    constexpr int g = decltype(gc)::value, kk = g / NPAIR, pp = g % NPAIR;
+                    constexpr int tt_in = kk / 2, ks = kk % 2;
+                    const int tt = sg * KT + tt_in;
+                    const int sidx = (tt % TPP) * 2 + ks;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const uint32_t idx = code_at<CB>(cur[tt / TPP][2 * pp + e], sidx, (uint32_t)nbits);
+                        dst[e] = lds_read16<0>(img_lane + (idx << shift));
+                    }
+                };
+                auto read_x = [&](auto kc, auto jc) {                      // activation fragment j of k-step kk
+                    constexpr int kk = decltype(kc)::value, j = decltype(jc)::value;
+                    constexpr int off = (kk / 2) * XT_BYTES + j * 2048;
+                    xfr[j] = lds_read16<off>((kk % 2) ? xs1 : xs0);
+                };
+                static_for<WT>([&](auto jc) { read_x(std::integral_constant<int, 0>{}, jc); });
+                gather_pair(std::integral_constant<int, 0>{}, P[0]);
+                static_for<NG>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value, kk = g / NPAIR, pp = g % NPAIR, c = g & 1;
+                    constexpr bool more = g + 1 < NG;
+                    constexpr bool reload = pp == NPAIR - 1 && kk + 1 < NKS;   // last group of a k-step
+                    if constexpr (more) gather_pair(std::integral_constant<int, more ? g + 1 : g>{}, P[c ^ 1]);
+                    constexpr int newer = more ? 2 : 0;                         // reads issued after this group's operands
+                    auto mfmas = [&](int j0, int j1) {
+#pragma unroll
+                        for (int j = j0; j < j1; ++j)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e)
+                                acc[2 * pp + e][j] = Act<AT>::mfma16(__builtin_bit_cast(vec8, P[c][e]),
+                                                                     __builtin_bit_cast(vec8, xfr[j]), acc[2 * pp + e][j]);
+                    };
+                    if constexpr (pp == 0 && kk > 0) {
+                        // this k-step's activations were requested in two halves behind the previous group's MFMAs
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(P[c][0]), "+v"(P[c][1]) : "n"(newer + H));
+#pragma unroll
+                        for (int j = 0; j < H; ++j) asm volatile("" : "+v"(xfr[j]));
+                        mfmas(0, H);
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(newer));
+#pragma unroll
+                        for (int j = H; j < WT; ++j) asm volatile("" : "+v"(xfr[j]));
+                        mfmas(H, WT);
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(P[c][0]), "+v"(P[c][1]) : "n"(newer));
+                        if constexpr (pp == 0) {
+#pragma unroll
+                            for (int j = 0; j < WT; ++j) asm volatile("" : "+v"(xfr[j]));
+                        }
+                        if constexpr (reload) {
+                            mfmas(0, H);
+                            __builtin_amdgcn_sched_barrier(0);
+                            static_for<H>([&](auto jc) { read_x(std::integral_constant<int, reload ? kk + 1 : kk>{}, jc); });
+                            mfmas(H, WT);
+                            __builtin_amdgcn_sched_barrier(0);
+                            static_for<H>([&](auto jc) {
+                                read_x(std::integral_constant<int, reload ? kk + 1 : kk>{},
+                                       std::integral_constant<int, decltype(jc)::value + H>{});
+                            });
+                        } else {
+                            mfmas(0, WT);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else {
 #pragma unroll
             for (int it = 0; it < KT; ++it) {
                 const int tt = sg * KT + it;           // tile within the loop step (compile-time)
@@ -234,7 +342,12 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
 #pragma unroll
                     for (int j = 0; j < WT; ++j) {
                         const int row = (wt * WT + j) * 16 + r16;
-                        xf[j] = *reinterpret_cast<const vec8 *>(xb + xt_off(row, ks * 4 + q));
+                        if constexpr (ABL & 16) {
+                            const u32x4 fake{(uint32_t)row * 0x3f1u | 0x3f003f00u, 0x3f803f80u, (uint32_t)lane | 0x3f003f00u, 0x40004000u};
+                            xf[j] = __builtin_bit_cast(vec8, fake);
+                        } else {
+                            xf[j] = *reinterpret_cast<const vec8 *>(xb + xt_off(row, ks * 4 + q));
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < WN; ++i) {
@@ -258,6 +371,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
                         for (int j = 0; j < WT; ++j) acc[i][j] = Act<AT>::mfma16(a, xf[j], acc[i][j]);
                     }
                 }
+            }
             }
             if constexpr (!(ABL & 1)) {
                 // younger than the DMA of stage st+1: this stage's DMA and, in a step's first stage, its code loads
