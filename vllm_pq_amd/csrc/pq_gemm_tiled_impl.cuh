@@ -95,6 +95,8 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     typedef uint32_t piece_t __attribute__((ext_vector_type(PW)));
     // hand-pipelined LDS reads in the main loop: d = 8, one codebook, fragments taken in pairs
     constexpr bool PIPE = D == 8 && M == 1 && WN % 2 == 0 && WT % 2 == 0 && !(ABL & (8 | 16));
+    // the same format on the shapes with a single weight fragment per wave: hand-issued reads, in batches of k-steps
+    constexpr bool BATCH = D == 8 && M == 1 && !PIPE && !(ABL & (8 | 16));
     static_assert(KS % 2 == 0 && U % TPP == 0 && U % KT == 0, "pieces and stages must tile the loop step");
     static_assert(PPW >= 1, "tile too small for the block");
 
@@ -328,6 +330,57 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
                             mfmas(0, WT);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else if constexpr (BATCH) {
+                // Few MFMAs per k-step (small tiles): the operands of NB k-steps are requested in one go and
+                // consumed after a single wait, one batch ahead of the MFMAs (two register sets), instead of
+                // one LDS round trip per k-step.
+                constexpr int NKS = KT * 2;
+                constexpr int REGS_PER_KS = 4 * (WT + WN);
+                constexpr int NB0 = 48 / REGS_PER_KS;
+                constexpr int NB = NB0 >= NKS ? NKS : NB0 >= 4 ? 4 : NB0 >= 2 ? 2 : 1;
+                constexpr int NBATCH = NKS / NB;
+                const uint32_t xs0 = xlane[0] + (uint32_t)buf * STAGE_BYTES, xs1 = xlane[1] + (uint32_t)buf * STAGE_BYTES;
+                u32x4 xr[2][NB][WT], ar[2][NB][WN];
+                auto issue = [&](auto bc) {
+                    constexpr int b = decltype(bc)::value, slot = b & 1;
+                    static_for<NB>([&](auto kbc) {
+                        constexpr int kb = decltype(kbc)::value, kk = b * NB + kb, it = kk / 2, ks = kk % 2;
+                        const int tt = sg * KT + it;
+                        const int sidx = (tt % TPP) * 2 + ks;
+                        static_for<WT>([&](auto jc) {
+                            constexpr int j = decltype(jc)::value;
+                            xr[slot][kb][j] = lds_read16<it * XT_BYTES + j * 2048>(ks ? xs1 : xs0);
+                        });
+#pragma unroll
+                        for (int i = 0; i < WN; ++i) {
+                            const uint32_t idx = code_at<CB>(cur[tt / TPP][i], sidx, (uint32_t)nbits);
+                            ar[slot][kb][i] = lds_read16<0>(img_lane + (idx << shift));
+                        }
+                    });
+                };
+                issue(std::integral_constant<int, 0>{});
+                static_for<NBATCH>([&](auto bc) {
+                    constexpr int b = decltype(bc)::value, slot = b & 1;
+                    constexpr bool more = b + 1 < NBATCH;
+                    if constexpr (more) issue(std::integral_constant<int, more ? b + 1 : b>{});
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(more ? NB * (WT + WN) : 0));
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+                        for (int j = 0; j < WT; ++j) asm volatile("" : "+v"(xr[slot][kb][j]));
+#pragma unroll
+                        for (int i = 0; i < WN; ++i) asm volatile("" : "+v"(ar[slot][kb][i]));
+                    }
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                        for (int i = 0; i < WN; ++i)
+#pragma unroll
+                            for (int j = 0; j < WT; ++j)
+                                acc[i][j] = Act<AT>::mfma16(__builtin_bit_cast(vec8, ar[slot][kb][i]),
+                                                            __builtin_bit_cast(vec8, xr[slot][kb][j]), acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             } else {
