@@ -256,3 +256,98 @@ def test_ops_reject_cpu_tensors_and_bad_shapes(ops):
         ops.pq_gemm(p.x_dev, p.codes_dev, p.codebooks_dev, p.scales_dev, [32, 16], None)   # sum != N, P*M mismatch
     with pytest.raises(ValueError):
         ops.pq_gemm(p.x_dev[:, :64], p.codes_dev, p.codebooks_dev, p.scales_dev, [64], None)
+
+
+# ---- every tile shape of both MFMA kernels, forced one by one ----------------------------------------
+def _device_reference(ops, p, parts):
+    """fp32 matmul over the (bit-exact) dequantised weight, on the device: (y_ref, rms)."""
+    w = ops.pq_dequant(p.codes_dev, p.codebooks_dev, parts)
+    ref = (p.x_dev.float() @ w.float().t()) * p.scales_dev.view(1, -1).float()
+    if p.bias_dev is not None:
+        ref = ref + p.bias_dev.float()
+    return ref, ref.pow(2).mean().sqrt()
+
+
+@pytest.mark.parametrize("cfg", range(7))
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_tiled_kernel_every_tile_shape(ops, monkeypatch, cfg, dtype):
+    """Partial row tiles in both partitions, a partial token tile, bias; the shape is forced, so the largest
+    ones run far below their efficient size -- this checks indexing, not speed."""
+    parts, Kin, T = [528, 272], 1024, 200
+    p = Problem(77 + cfg, 256, 8, 1, parts, Kin, T, dtype, bias=True).to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "tiled")
+    monkeypatch.setenv("PQ_AMD_TILED_CFG", str(cfg))
+    y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    y2 = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    assert torch.equal(y, y2)                                   # run-to-run identical bits
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(y), y32, dtype, f"tiled cfg {cfg}")
+
+
+@pytest.mark.parametrize("fmt", [(256, 4, 1), (16, 2, 1), (4096, 8, 1), (256, 8, 2)])
+@pytest.mark.parametrize("cfg", [0, 2, 5, 6])
+def test_tiled_kernel_other_formats_tile_shapes(ops, monkeypatch, fmt, cfg):
+    K, d, M = fmt
+    parts, Kin, T = [272, 144], 1024, 150
+    p = Problem(5 + cfg, K, d, M, parts, Kin, T, "bf16", bias=False).to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    assert packed is not None
+    monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "tiled")
+    monkeypatch.setenv("PQ_AMD_TILED_CFG", str(cfg))
+    y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(y), y32, "bf16", f"K={K} d={d} M={M} cfg {cfg}")
+
+
+@pytest.mark.parametrize("cfg,T", [("1x1", 3), ("2x1", 16), ("4x1", 9), ("7x1", 16), ("8x1", 1), ("4x2", 30),
+                                   ("4x2", 70), ("2x4", 64), ("4x4", 100)])
+def test_stream_kernel_every_tile_shape(ops, monkeypatch, cfg, T):
+    """K spans 2.5 chunks per wave set (ragged last chunk), rows leave partial tiles for every NF."""
+    parts, Kin = [400, 176], 1280
+    p = Problem(31, 256, 8, 1, parts, Kin, T, "bf16", bias=True).to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "stream")
+    monkeypatch.setenv("PQ_AMD_STREAM_CFG", cfg)
+    y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    y2 = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    assert torch.equal(y, y2)
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(y), y32, "bf16", f"stream cfg {cfg}")
+
+
+def test_tiled_kernel_strided_activations(ops):
+    parts, Kin, T = [512], 1024, 100
+    p = Problem(8, 256, 8, 1, parts, Kin, T, "bf16").to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    want = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)
+    wide = torch.randn(T, 2048, device=DEV).to(torch.bfloat16)
+    wide[:, 512:1536] = p.x_dev
+    got = ops.pq_gemm_packed(wide[:, 512:1536], packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("name,parts,Kin", [
+    ("qkv_proj", [4096, 1024, 1024], 4096), ("o_proj", [4096], 4096),
+    ("gate_up_proj", [14336, 14336], 4096), ("down_proj", [4096], 14336)])
+@pytest.mark.parametrize("T", [1, 16, 64, 300, 4096])
+def test_llama3_8b_full_size_packed_path(ops, name, parts, Kin, T):
+    """The production path at BASELINE sizes: packed codes, whichever kernel and tile shape the dispatch
+    picks at this T, against an fp32 matmul over the bit-exact dequantised weight (on the device)."""
+    torch.manual_seed(T)
+    N, G = sum(parts), Kin // 8
+    codes = torch.randint(-128, 128, (N, G, 1), dtype=torch.int8, device=DEV)
+    cb = torch.randn(len(parts), 256, 1, 8, device=DEV).to(torch.bfloat16)
+    scales = (torch.rand(N, 1, 1, 1, device=DEV) + 0.5).to(torch.bfloat16)
+    x = torch.randn(T, Kin, device=DEV).to(torch.bfloat16)
+    packed = ops.pq_repack_codes(codes, cb, parts)
+    y = ops.pq_gemm_packed(x, packed, codes, cb, scales, parts, None)
+    w = ops.pq_dequant(codes, cb, parts)
+    ref = (x.float() @ w.float().t()) * scales.view(1, -1).float()
+    rms = ref.pow(2).mean().sqrt()
+    tol = 0.51 * 2.0 ** -7 * ref.abs() + 1e-4 * rms        # fp32 reference itself carries ~1e-5 rms noise
+    bad = (y.float() - ref).abs() > tol
+    assert not bad.any(), f"{name} T={T}: {int(bad.sum())} of {bad.numel()} outside tolerance"
+    # linearity in x (size-independent property): y(2x) == 2 y(x) exactly in binary floating point
+    y2 = ops.pq_gemm_packed(x * 2, packed, codes, cb, scales, parts, None)
+    assert torch.equal(y2, y * 2)

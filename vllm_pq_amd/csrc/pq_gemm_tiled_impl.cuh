@@ -299,36 +299,32 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
                                 acc[2 * pp + e][j] = Act<AT>::mfma16(__builtin_bit_cast(vec8, P[c][e]),
                                                                      __builtin_bit_cast(vec8, xfr[j]), acc[2 * pp + e][j]);
                     };
-                    if constexpr (pp == 0 && kk > 0) {
-                        // this k-step's activations were requested in two halves behind the previous group's MFMAs
-                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(P[c][0]), "+v"(P[c][1]) : "n"(newer + H));
+                    constexpr bool halves = pp == 0 && kk > 0;   // this k-step's activations were requested in two
+                                                                 // halves behind the previous group's MFMAs
+                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(P[c][0]), "+v"(P[c][1]) : "n"(newer + (halves ? H : 0)));
+                    if constexpr (pp == 0) {
 #pragma unroll
-                        for (int j = 0; j < H; ++j) asm volatile("" : "+v"(xfr[j]));
-                        mfmas(0, H);
+                        for (int j = 0; j < (halves ? H : WT); ++j) asm volatile("" : "+v"(xfr[j]));
+                    }
+                    mfmas(0, H);
+                    if constexpr (reload) {
                         __builtin_amdgcn_sched_barrier(0);
-                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(newer));
+                        static_for<H>([&](auto jc) { read_x(std::integral_constant<int, reload ? kk + 1 : kk>{}, jc); });
+                    }
+                    if constexpr (halves) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        // newer than the second half: the next group's gathers and, if issued, the first half's re-reads
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(newer + (reload ? H : 0)));
 #pragma unroll
                         for (int j = H; j < WT; ++j) asm volatile("" : "+v"(xfr[j]));
-                        mfmas(H, WT);
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(P[c][0]), "+v"(P[c][1]) : "n"(newer));
-                        if constexpr (pp == 0) {
-#pragma unroll
-                            for (int j = 0; j < WT; ++j) asm volatile("" : "+v"(xfr[j]));
-                        }
-                        if constexpr (reload) {
-                            mfmas(0, H);
-                            __builtin_amdgcn_sched_barrier(0);
-                            static_for<H>([&](auto jc) { read_x(std::integral_constant<int, reload ? kk + 1 : kk>{}, jc); });
-                            mfmas(H, WT);
-                            __builtin_amdgcn_sched_barrier(0);
-                            static_for<H>([&](auto jc) {
-                                read_x(std::integral_constant<int, reload ? kk + 1 : kk>{},
-                                       std::integral_constant<int, decltype(jc)::value + H>{});
-                            });
-                        } else {
-                            mfmas(0, WT);
-                        }
+                    }
+                    mfmas(H, WT);
+                    if constexpr (reload) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        static_for<H>([&](auto jc) {
+                            read_x(std::integral_constant<int, reload ? kk + 1 : kk>{},
+                                   std::integral_constant<int, decltype(jc)::value + H>{});
+                        });
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
