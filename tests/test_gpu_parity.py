@@ -351,3 +351,52 @@ def test_llama3_8b_full_size_packed_path(ops, name, parts, Kin, T):
     # linearity in x (size-independent property): y(2x) == 2 y(x) exactly in binary floating point
     y2 = ops.pq_gemm_packed(x * 2, packed, codes, cb, scales, parts, None)
     assert torch.equal(y2, y * 2)
+
+
+# ---- K split over blocks (workspace) -----------------------------------------------------------------
+@pytest.mark.parametrize("T", [1, 7, 16, 40, 100])
+@pytest.mark.parametrize("ksplit", [2, 3, 4, 8])
+def test_stream_kernel_k_split(ops, monkeypatch, T, ksplit):
+    """Partial sums through the workspace, last block adds them up: within tolerance of the oracle, identical
+    bits run to run, counters left at zero (a second and third launch reuse them), no split without a workspace."""
+    parts, Kin = [208, 112], 512 * 11            # 11 chunks: uneven ranges for every split
+    p = Problem(41 + ksplit, 256, 8, 1, parts, Kin, T, "bf16", bias=True).to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "stream")
+    monkeypatch.setenv("PQ_AMD_STREAM_KSPLIT", str(ksplit))
+    N, G = p.N, p.G
+    need = ops.workspace_bytes(T, N, G, 1, 256, 8, 1, torch.bfloat16)
+    assert need == 16384 + ksplit * T * N * 4
+    ops.drop_workspace()
+    y_plain = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    ops.ensure_workspace(torch.device(DEV), need)
+    try:
+        ys = [ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+              for _ in range(3)]
+        torch.cuda.synchronize()
+        ws = ops._WORKSPACE[torch.device(DEV).index or 0]
+        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0
+    finally:
+        ops.drop_workspace()
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(ys[0]), y32, "bf16", f"ksplit {ksplit}")
+    assert_close_to_exact(bits_of(y_plain), y32, "bf16", "no workspace")
+
+
+def test_k_split_default_on_long_k_layers(ops):
+    """down_proj-like shape: the library asks for a workspace, and with one the result stays within tolerance."""
+    parts, Kin, T = [512], 14336, 16
+    p = Problem(3, 256, 8, 1, parts, Kin, T, "bf16").to(DEV)
+    need = ops.workspace_bytes(T, p.N, p.G, 1, 256, 8, 1, torch.bfloat16)
+    assert need > 0
+    assert ops.workspace_bytes(T, p.N, 512, 1, 256, 8, 1, torch.bfloat16) == 0      # K = 4096: never split
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    ops.ensure_workspace(torch.device(DEV), need)
+    try:
+        y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)
+    finally:
+        ops.drop_workspace()
+    ref, rms = _device_reference(ops, p, parts)
+    tol = 0.51 * 2.0 ** -7 * ref.abs() + 1e-4 * rms
+    assert ((y.float() - ref).abs() <= tol).all()

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--natural", action="store_true", help="reference code layout instead of the packed one")
+    ap.add_argument("--workspace", action="store_true", help="give the library its K-split workspace")
     ap.add_argument("--copies", type=int, default=0, help="weight copies to rotate over (0: enough for 600 MB)")
     ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
@@ -47,6 +48,9 @@ def main():
             ws.append((codes, cbk, sc, pk))
         for T in [int(t) for t in args.tokens.split(",")]:
             x = torch.randn(T, kin, device=dev).to(dt)
+            ops.drop_workspace()
+            if args.workspace:
+                ops.ensure_workspace(torch.device(dev), ops.workspace_bytes(T, N, G, 1, args.K, args.d, cb_bytes, dt))
 
             def call(w):
                 if w[3] is not None:

@@ -36,7 +36,7 @@ float run(const char *label, int T, int N, int G, int nparts, int copies, int nw
     auto launch = [&](int i) {
         hipLaunchKernelGGL((gemm_stream_kernel<bf16_t, int8_t, D, M, NF, 1, true, ABL>), grid, dim3(ST_THREADS), lds, 0,
                            (const uint16_t *)x, T, (int64_t)G * D, (const void *)pk[i % copies], (const uint16_t *)cb,
-                           (const uint16_t *)sc, (const uint16_t *)nullptr, make_tile_map(parts, NF * 16), G, K, 8, R, (uint16_t *)y, (int64_t)N);
+                           (const uint16_t *)sc, (const uint16_t *)nullptr, make_tile_map(parts, NF * 16), G, K, 8, R, (uint16_t *)y, (int64_t)N, 1, nullptr, nullptr);
     };
     for (int i = 0; i < nwarm; ++i) launch(i);
     CK(hipDeviceSynchronize());

@@ -33,7 +33,7 @@ void run(const char *label, int T, int N, int G, int nparts) {
     for (int i = 0; i < copies; ++i) {
         hipLaunchKernelGGL((gemm_stream_kernel<bf16_t, int8_t, D, M, NF, TF, true, 64>), grid, dim3(ST_THREADS), lds, 0,
                            (const uint16_t *)x, T, (int64_t)G * D, (const void *)pk[i], (const uint16_t *)cb,
-                           (const uint16_t *)sc, (const uint16_t *)st, make_tile_map(parts, NF * 16), G, K, 8, R, (uint16_t *)y, (int64_t)N);
+                           (const uint16_t *)sc, (const uint16_t *)st, make_tile_map(parts, NF * 16), G, K, 8, R, (uint16_t *)y, (int64_t)N, 1, nullptr, nullptr);
         CK(hipDeviceSynchronize());
     }
     std::vector<unsigned long long> h((size_t)nblk * 8);

@@ -113,8 +113,10 @@ int pq_dequant(const void *codes, const void *codebooks, const void *scales, con
     return PQ_OK;
 }
 
-size_t pq_gemm_workspace_bytes(int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t) {
-    return 0;  // no kernel of this build needs scratch
+size_t pq_gemm_workspace_bytes(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes,
+                               int32_t /*dtype*/) {
+    if (T <= 0 || N <= 0 || G <= 0) return 0;
+    return pq::stream_workspace_bytes(T, N, G, M, K, d, code_bytes);
 }
 
 static int fill_gemm(pq::GemmArgs &a, const char *fn, const void *x, int32_t T, int64_t x_row_stride,

@@ -55,48 +55,104 @@ static bool stream_light_format(const GemmArgs &a) { return a.d == 8 && a.M == 1
 // sum) plus 1.9 us per activation sub-load of a wave: with more than 16 tokens the round trips of the
 // activation loads to L2, only one sub-chunk ahead, set the pace, not the code stream or the MFMAs.  A
 // sub-load is 32 registers, i.e. 8 / TF k-steps of the chunk's KS.
-static double stream_model_us(const GemmArgs &a, int nf, int tf) {
+static double stream_model_us(const GemmArgs &a, int nf, int tf, int ksplit) {
     const int cg = chunk_groups(a.code_bytes, a.M);
     const int ks = (cg / 4) * a.d / 8;                               // k-steps per chunk
-    const double nchunks = (double)((a.G + cg - 1) / cg);
-    const long blocks = (long)tiles_in(a.parts, nf * 16) * ((a.T + 16 * tf - 1) / (16 * tf));
+    const double nchunks = (double)((a.G + cg - 1) / cg) / ksplit;   // per block
+    const long blocks = (long)tiles_in(a.parts, nf * 16) * ((a.T + 16 * tf - 1) / (16 * tf)) * ksplit;
     const double rounds = (double)((blocks + 255) / 256);
     const double per_wave = nchunks / 8.0 < 1.0 ? 1.0 : nchunks / 8.0;
     const int subk = 8 / tf < ks ? 8 / tf : ks;
-    return rounds * (4.0 + per_wave * (ks / subk) * 1.9);
+    return rounds * (4.0 + (ksplit > 1 ? 2.0 : 0.0) + per_wave * (ks / subk) * 1.9);   // + 2 us: partial sums, count, re-read
+}
+
+// ---- K split over blocks ---------------------------------------------------------------------------
+// Decode batches on a layer with few rows and a long K (down_proj: 4096 x 14336) leave two bad choices
+// without it: 16-row tiles (one block per CU, but every block then reads all of x -- 16 x the bytes of its
+// codes at 16 tokens) or taller tiles (less x traffic, a quarter of the CUs idle).  With the K range of a
+// tile spread over `ksplit` blocks the tile can be tall and the grid full.
+// `forced`: PQ_AMD_STREAM_KSPLIT (tests and tuning), 0 when unset.  Otherwise up to 4 blocks per tile when K has
+// at least 24 chunks, 2 from 16, and only up to 128 tokens (larger batches fill the chip without it).
+static int ksplit_limit(int T, int G, int M, int code_bytes, int *forced) {
+    const char *env = getenv("PQ_AMD_STREAM_KSPLIT");
+    const int cg = chunk_groups(code_bytes, M);
+    const int nchunks = (G + cg - 1) / cg;
+    int s = nchunks >= 24 ? 4 : nchunks >= 16 ? 2 : 1;
+    *forced = 0;
+    if (env && *env) s = *forced = atoi(env);
+    if (T > 128) s = 1;
+    if (s > nchunks) s = nchunks;
+    s = s < 1 ? 1 : s > 8 ? 8 : s;
+    if (*forced) *forced = s;
+    return s;
+}
+
+bool stream_ksplit_ok(const GemmArgs &a, int nf, int tf, int ksplit) {
+    if (ksplit <= 1) return ksplit == 1;
+    if (!a.packed || !a.workspace || a.workspace_bytes <= WS_COUNTER_BYTES) return false;
+    int forced;
+    if (ksplit > ksplit_limit(a.T, a.G, a.M, a.code_bytes, &forced)) return false;
+    const long tiles = (long)tiles_in(a.parts, nf * 16) * ((a.T + 16 * tf - 1) / (16 * tf));
+    if (tiles * 4 > (long)WS_COUNTER_BYTES) return false;
+    if ((size_t)ksplit * a.T * a.N * 4 > a.workspace_bytes - WS_COUNTER_BYTES) return false;
+    return !(reinterpret_cast<uintptr_t>(a.workspace) & 15);
+}
+
+size_t stream_workspace_bytes(int T, int N, int G, int M, int K, int d, int code_bytes) {
+    if (!stream_format_supported(d, K, M, code_bytes)) return 0;
+    int forced;
+    const int s = ksplit_limit(T, G, M, code_bytes, &forced);
+    if (s == 1) return 0;
+    const size_t part = (size_t)s * T * N * 4;
+    return part > WS_PARTIAL_BYTES ? 0 : WS_COUNTER_BYTES + part;
 }
 
 StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {
     const bool light = stream_light_format(a), packed = a.packed;
     if (model_us) *model_us = 0.0;
+    int forced;
+    const int smax = ksplit_limit(a.T, a.G, a.M, a.code_bytes, &forced);
+    auto split_for = [&](int nf, int tf, int want) { return stream_ksplit_ok(a, nf, tf, want) ? want : 1; };
     const char *env = getenv("PQ_AMD_STREAM_CFG");   // "NFxTF", for tuning
     if (env && *env) {
         int nf = 0, tf = 0;
         if (sscanf(env, "%dx%d", &nf, &tf) == 2) {
             const bool ok1 = tf == 1 && (nf == 1 || nf == 2 || (light && (nf == 4 || (packed && (nf == 7 || nf == 8)))));
             const bool okw = packed && ((nf == 4 && tf == 4 && light) || (nf == 4 && tf == 2) || (nf == 2 && tf == 4));
-            if (ok1 || okw) return StreamCfg{nf, tf};
+            if (ok1 || okw) return StreamCfg{nf, tf, split_for(nf, tf, forced ? forced : 1)};
         }
     }
     if (!packed || a.T <= 16) {
-        // one token fragment: the code stream from HBM is the bound; about one block per CU
+        // One token fragment.  Measured on the MI355X (T = 16, K = 4096): a launch whose blocks fit one round
+        // (one block per CU) lasts about 6.3 us + 0.5 us per weight fragment of the tile, and blocks beyond
+        // 256 add time in proportion -- so prefer the shape whose grid just fits the chip.  From 4 tokens on
+        // a long K is split over blocks when it can be: each block then reads only its slice of x.
         static const int cand[] = {8, 7, 4, 2, 1};
+        StreamCfg best{1, 1, 1};
+        double best_cost = -1.0;
         for (int nf : cand) {
             if (nf > 2 && !light) continue;
             if (nf > 4 && !packed) continue;
-            if (tiles_in(a.parts, nf * 16) >= 224) return StreamCfg{nf, 1};
+            const int ks = split_for(nf, 1, forced ? forced : a.T >= 4 ? smax : 1);
+            const double blocks = (double)tiles_in(a.parts, nf * 16) * ks;
+            const double cost = (blocks > 256.0 ? blocks / 256.0 : 1.0) * (6.3 + 0.5 * nf);
+            if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = StreamCfg{nf, 1, ks}; }
         }
-        return StreamCfg{1, 1};
+        return best;
     }
-    // 17 tokens and more: the shape with the shortest modelled launch
-    static const StreamCfg wide[] = {{4, 4}, {2, 4}, {4, 2}};
+    // 17 tokens and more: the shape and split with the shortest modelled launch
+    static const StreamCfg wide[] = {{4, 4, 1}, {2, 4, 1}, {4, 2, 1}};
     StreamCfg best = wide[2];
     double best_us = -1.0;
     for (const StreamCfg &c : wide) {
         if (c.nf == 4 && c.tf == 4 && !light) continue;
         if (c.tf == 4 && a.T <= 32) continue;   // half the token tile would be padding
-        const double us = stream_model_us(a, c.nf, c.tf);
-        if (best_us < 0.0 || us < best_us) { best_us = us; best = c; }
+        for (int want = 1; want <= smax; want *= 2) {
+            if (forced && want != 1) continue;
+            const int ks = split_for(c.nf, c.tf, forced ? forced : want);
+            const double us = stream_model_us(a, c.nf, c.tf, ks);
+            if (best_us < 0.0 || us < best_us) { best_us = us; best = StreamCfg{c.nf, c.tf, ks}; }
+        }
     }
     if (model_us) *model_us = best_us;
     return best;

@@ -46,7 +46,8 @@ template <typename AT, typename CodeT, int D, int M, int NF, int TF, bool PACKED
 __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
     const uint16_t *__restrict__ x, int T, int64_t x_stride, const void *__restrict__ codes_v,
     const uint16_t *__restrict__ codebooks, const uint16_t *__restrict__ scales, const uint16_t *__restrict__ bias,
-    TileMap tmap, int G, int K, int nbits, int R, uint16_t *__restrict__ y, int64_t y_stride) {
+    TileMap tmap, int G, int K, int nbits, int R, uint16_t *__restrict__ y, int64_t y_stride, int ksplit,
+    float *__restrict__ ws_part, unsigned *__restrict__ ws_cnt) {
     typedef typename Act<AT>::vec8 vec8;
     typedef StreamFmt<sizeof(CodeT), D, M> F;
     constexpr int CB = sizeof(CodeT);
@@ -76,11 +77,17 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
     const int r16 = lane & 15;   // weight row within a fragment (A) / token within a fragment (B)
     const int q = lane >> 4;     // k quad
 
-    const TileLoc loc = locate_tile(tmap, blockIdx.x, NF * 16);
+    // K may be split over `ksplit` blocks per tile (grid.x = ksplit * tiles): block z of a tile takes a
+    // contiguous range of chunks and the tile's last block to finish adds the partial sums up (see the end)
+    const int n_tiles_x = (int)gridDim.x / ksplit;
+    const int zsplit = (int)blockIdx.x / n_tiles_x;
+    const int tile_x = (int)blockIdx.x - zsplit * n_tiles_x;
+    const TileLoc loc = locate_tile(tmap, tile_x, NF * 16);
     const int t0 = blockIdx.y * (16 * TF);
     const int row_end = loc.row0 + loc.nrows;
     const int Kin = G * D;
     const int nchunks = (G + CG - 1) / CG;
+    const int c_begin = zsplit * nchunks / ksplit, c_end = (zsplit + 1) * nchunks / ksplit;   // this block's chunks
 
     f32x4 acc[NF][TF];
 #pragma unroll
@@ -196,9 +203,9 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
         img.load(reinterpret_cast<const unsigned char *>(codebooks) + (size_t)loc.part * M * K * EB, M * K, R, tid);
     Codes cA, cB;
     XSub X[2];
-    if (wave < nchunks) {
-        load_codes(cA, wave);
-        load_x(X[0], wave, 0);
+    if (c_begin + wave < c_end) {
+        load_codes(cA, c_begin + wave);
+        load_x(X[0], c_begin + wave, 0);
     }
     // ---- epilogue operands: this thread's output rows in each reduction round.  Fetched now, behind the
     // streaming loads and without touching the loaded registers, so that no global load sits on the tail.
@@ -223,9 +230,9 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
 
     // ---- chunks wave, wave + 8, ...: two per iteration so that every register set has a fixed name.
     // The next sub-chunk's activations and the next chunk's codes are in flight while one is computed.
-    for (int c = wave; c < nchunks; c += 2 * ST_WAVES) {
+    for (int c = c_begin + wave; c < c_end; c += 2 * ST_WAVES) {
         const int c1 = c + ST_WAVES, c2 = c + 2 * ST_WAVES;
-        const bool m1 = c1 < nchunks, m2 = c2 < nchunks;
+        const bool m1 = c1 < c_end, m2 = c2 < c_end;
         if (m1) load_codes(cB, c1);
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
@@ -259,6 +266,25 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
         if (tid == 0) stamps[3] = wall_clock64();   // this wave's MFMAs done
     }
     // ---- deterministic cross-wave sum through LDS (the codebook image is dead now), RF fragments a round
+    // scale, bias, round to the act dtype, store: thread-private (token t, rows nb .. nb+3) of round r
+    auto finish = [&](int r, const f32x4 &sum, int t, int nb) {
+        uint16_t h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            h[e] = Act<AT>::from_f32(sum[e] * Act<AT>::to_f32(sc_raw[r][e]) + Act<AT>::to_f32(bi_raw[r][e]));
+        uint16_t *yp = y + (size_t)t * y_stride + nb;
+        if (nb + 4 <= row_end && (reinterpret_cast<uintptr_t>(yp) & 7) == 0) {
+            u32x2 o2;
+            o2.x = h[0] | ((uint32_t)h[1] << 16);
+            o2.y = h[2] | ((uint32_t)h[3] << 16);
+            *reinterpret_cast<u32x2 *>(yp) = o2;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (nb + e < row_end) yp[e] = h[e];
+        }
+    };
+    const bool split = ksplit > 1;
     f32x4 *red = reinterpret_cast<f32x4 *>(smem);   // [wave][RF][64]
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
@@ -283,20 +309,50 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
             const int t = t0 + 16 * (fr % TF) + r16;
             const int nb = loc.row0 + 16 * (fr / TF) + q * 4;
             if (t < T && nb < row_end) {
-                uint16_t h[4];
+                if (!split) finish(r, sum, t, nb);
+                else {
+                    float *pp = ws_part + ((size_t)zsplit * T + t) * (size_t)tmap.row_end[PQ_MAX_PARTS - 1] + nb;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    h[e] = Act<AT>::from_f32(sum[e] * Act<AT>::to_f32(sc_raw[r][e]) + Act<AT>::to_f32(bi_raw[r][e]));
-                uint16_t *yp = y + (size_t)t * y_stride + nb;
-                if (nb + 4 <= row_end && (reinterpret_cast<uintptr_t>(yp) & 7) == 0) {
-                    u32x2 o2;
-                    o2.x = h[0] | ((uint32_t)h[1] << 16);
-                    o2.y = h[2] | ((uint32_t)h[3] << 16);
-                    *reinterpret_cast<u32x2 *>(yp) = o2;
-                } else {
+                    for (int e = 0; e < 4; ++e) __hip_atomic_store(pp + e, sum[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+    // ---- K split over blocks: partial sums [ksplit][T][N] fp32 in the workspace; every block counts itself
+    // in on its tile's counter and the last one to arrive adds the partials up in split order (so the result
+    // does not depend on which block that is), finishes the tile and leaves the counter at zero again.
+    // Partials and counter are written and read with device-scope relaxed atomics (coherent accesses that
+    // go past the per-XCD L2), ordered by waiting for the stores' completion before the count: a device-
+    // scope fence would write back and invalidate the whole L2 instead, tens of microseconds per launch.
+    if (split) {
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partials have been written ...
+        __syncthreads();                                    // ... and so have the block's
+        if (tid == 0) {
+            unsigned *cnt = ws_cnt + (size_t)blockIdx.y * n_tiles_x + tile_x;
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (unsigned)ksplit - 1u;
+            if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_last) {
+            const size_t n_total = (size_t)tmap.row_end[PQ_MAX_PARTS - 1];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (nb + e < row_end) yp[e] = h[e];
+            for (int r = 0; r < ROUNDS; ++r) {
+                if (tid < RF * 64) {
+                    const int fr = r * RF + (tid >> 6);
+                    const int t = t0 + 16 * (fr % TF) + r16;
+                    const int nb = loc.row0 + 16 * (fr / TF) + q * 4;
+                    if (t < T && nb < row_end) {
+                        f32x4 sum{0.f, 0.f, 0.f, 0.f};
+                        for (int z = 0; z < ksplit; ++z) {
+                            const float *pp = ws_part + ((size_t)z * T + t) * n_total + nb;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                sum[e] += __hip_atomic_load(pp + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        finish(r, sum, t, nb);
+                    }
                 }
             }
         }
@@ -309,19 +365,22 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
 
 // ---- per-dtype launcher (instantiated once per act dtype, in its own translation unit) --------
 template <typename AT, typename CodeT, int D, int M, int NF, int TF, bool PACKED>
-static hipError_t launch_nf(const GemmArgs &a, hipStream_t stream) {
+static hipError_t launch_nf(const GemmArgs &a, int ksplit, hipStream_t stream) {
     const int R = stream_replication<D>(a.K, a.M);
     const int nbits = __builtin_ctz((unsigned)a.K);
     constexpr int RF = NF * TF < 8 ? NF * TF : 8;
     size_t lds = (size_t)a.M * a.K * 2 * D * R;
     const size_t red = (size_t)ST_WAVES * RF * 64 * 16;
     if (red > lds) lds = red;
-    const dim3 grid(tiles_in(a.parts, NF * 16), (a.T + 16 * TF - 1) / (16 * TF));
+    const int n_tiles = tiles_in(a.parts, NF * 16);
+    const dim3 grid(n_tiles * ksplit, (a.T + 16 * TF - 1) / (16 * TF));
+    unsigned *ws_cnt = static_cast<unsigned *>(a.workspace);
+    float *ws_part = reinterpret_cast<float *>(static_cast<unsigned char *>(a.workspace) + WS_COUNTER_BYTES);
     hipLaunchKernelGGL((gemm_stream_kernel<AT, CodeT, D, M, NF, TF, PACKED>), grid, dim3(ST_THREADS), lds, stream,
                        static_cast<const uint16_t *>(a.x), a.T, a.x_stride, a.codes,
                        static_cast<const uint16_t *>(a.codebooks), static_cast<const uint16_t *>(a.scales),
                        static_cast<const uint16_t *>(a.bias), make_tile_map(a.parts, NF * 16), a.G, a.K, nbits, R,
-                       static_cast<uint16_t *>(a.y), a.y_stride);
+                       static_cast<uint16_t *>(a.y), a.y_stride, ksplit, ws_part, ws_cnt);
     return hipGetLastError();
 }
 
@@ -332,25 +391,25 @@ static hipError_t launch_fmt(const GemmArgs &a, hipStream_t stream) {
     if (a.packed) {
         if (c.tf == 4) {
             if constexpr (LIGHT)
-                if (c.nf == 4) return launch_nf<AT, CodeT, D, M, 4, 4, true>(a, stream);
-            return launch_nf<AT, CodeT, D, M, 2, 4, true>(a, stream);
+                if (c.nf == 4) return launch_nf<AT, CodeT, D, M, 4, 4, true>(a, c.ksplit, stream);
+            return launch_nf<AT, CodeT, D, M, 2, 4, true>(a, c.ksplit, stream);
         }
-        if (c.tf == 2) return launch_nf<AT, CodeT, D, M, 4, 2, true>(a, stream);
+        if (c.tf == 2) return launch_nf<AT, CodeT, D, M, 4, 2, true>(a, c.ksplit, stream);
         if constexpr (LIGHT) {
             switch (c.nf) {
-            case 8: return launch_nf<AT, CodeT, D, M, 8, 1, true>(a, stream);
-            case 7: return launch_nf<AT, CodeT, D, M, 7, 1, true>(a, stream);
-            case 4: return launch_nf<AT, CodeT, D, M, 4, 1, true>(a, stream);
+            case 8: return launch_nf<AT, CodeT, D, M, 8, 1, true>(a, c.ksplit, stream);
+            case 7: return launch_nf<AT, CodeT, D, M, 7, 1, true>(a, c.ksplit, stream);
+            case 4: return launch_nf<AT, CodeT, D, M, 4, 1, true>(a, c.ksplit, stream);
             default: break;
             }
         }
-        return c.nf == 2 ? launch_nf<AT, CodeT, D, M, 2, 1, true>(a, stream)
-                         : launch_nf<AT, CodeT, D, M, 1, 1, true>(a, stream);
+        return c.nf == 2 ? launch_nf<AT, CodeT, D, M, 2, 1, true>(a, c.ksplit, stream)
+                         : launch_nf<AT, CodeT, D, M, 1, 1, true>(a, c.ksplit, stream);
     }
     if constexpr (LIGHT)
-        if (c.nf == 4) return launch_nf<AT, CodeT, D, M, 4, 1, false>(a, stream);
-    return c.nf == 2 ? launch_nf<AT, CodeT, D, M, 2, 1, false>(a, stream)
-                     : launch_nf<AT, CodeT, D, M, 1, 1, false>(a, stream);
+        if (c.nf == 4) return launch_nf<AT, CodeT, D, M, 4, 1, false>(a, c.ksplit, stream);
+    return c.nf == 2 ? launch_nf<AT, CodeT, D, M, 2, 1, false>(a, c.ksplit, stream)
+                     : launch_nf<AT, CodeT, D, M, 1, 1, false>(a, c.ksplit, stream);
 }
 
 template <typename AT>

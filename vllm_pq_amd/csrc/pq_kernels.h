@@ -43,7 +43,16 @@ hipError_t launch_gemm_generic(const GemmArgs &a, hipStream_t stream);
 bool gemm_stream_supported(const GemmArgs &a);
 // Tile shape of the streaming kernel for this problem: NF 16-row weight fragments x TF 16-token fragments
 // per block.  *model_us (optional) receives the modelled launch duration for T > 16, 0 otherwise.
-struct StreamCfg { int nf, tf; };
+struct StreamCfg { int nf, tf, ksplit; };
+// Workspace layout of the K-split launches: WS_COUNTER_BYTES of per-tile arrival counters (zero between
+// launches), then the fp32 partial sums [ksplit][T][N].
+constexpr size_t WS_COUNTER_BYTES = 16384;
+constexpr size_t WS_PARTIAL_BYTES = (size_t)8 << 20;
+// Whether `ksplit` blocks may share one tile's K range in the streaming kernel for this problem and tile shape
+// (needs packed codes, a workspace that holds the partial sums, at most 4096 tiles).
+bool stream_ksplit_ok(const GemmArgs &a, int nf, int tf, int ksplit);
+// Bytes of workspace with which this problem may run K-split (0: it never does).
+size_t stream_workspace_bytes(int T, int N, int G, int M, int K, int d, int code_bytes);
 StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us);
 hipError_t launch_gemm_stream(const GemmArgs &a, hipStream_t stream);
 

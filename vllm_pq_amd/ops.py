@@ -65,6 +65,37 @@ def _raise(rc: int):
     raise RuntimeError(msg)
 
 
+# ---- workspace of the K-split launches ---------------------------------------------------------
+# One zero-initialised buffer per device, created at weight-load time (never inside an op, so never
+# under HIP-graph capture) and shared by every layer: launches on one stream run one after the
+# other, and a launch leaves the counters at its head zero again.  Launches issued concurrently on
+# several streams of one device must not share it: call drop_workspace() to run without.
+_WORKSPACE = {}
+
+
+def workspace_bytes(T: int, N: int, G: int, M: int, K: int, d: int, code_bytes: int, dtype: torch.dtype) -> int:
+    """Bytes of scratch with which pq_gemm may split K over several blocks for this problem (0: never)."""
+    return int(_lib.load().pq_gemm_workspace_bytes(T, N, G, M, K, d, code_bytes, _DTYPE[dtype]))
+
+
+def ensure_workspace(device: torch.device, nbytes: int) -> None:
+    """Make the device's workspace at least `nbytes` large.  Call at load time, outside graph capture."""
+    if nbytes <= 0:
+        return
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    cur = _WORKSPACE.get(idx)
+    if cur is None or cur.numel() < nbytes:
+        _WORKSPACE[idx] = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
+
+
+def drop_workspace(device: Optional[torch.device] = None) -> None:
+    if device is None:
+        _WORKSPACE.clear()
+    else:
+        _WORKSPACE.pop(torch.device(device).index, None)
+
+
 # ---- eager implementations ------------------------------------------------------------------
 def _pq_dequant_impl(codes: torch.Tensor, codebooks: torch.Tensor, codebook_partition_sizes: List[int],
                      scales: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -113,13 +144,15 @@ def _pq_gemm_impl(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Ten
         bias = bias.contiguous()
     out = torch.empty((T, N), dtype=input.dtype, device=dev)
     if T and N:
+        ws = _WORKSPACE.get(dev.index)
         with torch.cuda.device(dev):
             fn = L.pq_gemm if packed_codes is None else L.pq_gemm_packed
             cptr = codes.data_ptr() if packed_codes is None else packed_codes.data_ptr()
             rc = fn(x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, cptr,
                            codebooks.data_ptr(), scales.data_ptr(), bias.data_ptr() if bias is not None else None,
                            _lib.parts_array(parts), len(parts), N, G, M, K, d, _CODE_BYTES[codes.dtype],
-                           _DTYPE[input.dtype], out.data_ptr(), N, None, 0, _stream_ptr(dev))
+                           _DTYPE[input.dtype], out.data_ptr(), N, ws.data_ptr() if ws is not None else None,
+                           ws.numel() if ws is not None else 0, _stream_ptr(dev))
         if rc:
             _raise(rc)
     return out.reshape(input.shape[:-1] + (N,))
@@ -172,7 +205,7 @@ def pq_gemm_packed(input: torch.Tensor, packed_codes: torch.Tensor, codes: torch
                    scales: torch.Tensor, codebook_partition_sizes: List[int],
                    bias: Optional[torch.Tensor]) -> torch.Tensor:
     """pq_gemm reading the codes from `packed_codes` (pq_repack_codes); `codes` only supplies the
-    shape and dtype of the reference-layout tensor.  Same results as pq_gemm bit for bit."""
+    shape and dtype of the reference-layout tensor."""
     if _HAVE_CUSTOM_OP and input.is_cuda:
         return torch.ops.pq_amd.gemm_packed(input, packed_codes, codes, codebooks, scales,
                                             list(codebook_partition_sizes), bias)

@@ -156,6 +156,14 @@ class PQLinearMethod(LinearMethodBase):
         if layer.codes.is_cuda:
             parts = getattr(layer.codebooks, "output_partition_sizes", [])
             layer.pq_packed_codes = ops.pq_repack_codes(layer.codes.data, layer.codebooks.data, parts)
+            if layer.pq_packed_codes is not None:
+                # scratch for the K-split launches (long-K layers, up to 128 tokens): one buffer per device,
+                # sized here, at load time, for the largest batch those launches take
+                N, G, M = layer.codes.shape
+                K, d = layer.codebooks.shape[1], layer.codebooks.shape[3]
+                ops.ensure_workspace(layer.codes.device,
+                                     ops.workspace_bytes(128, N, G, M, K, d, layer.codes.element_size(),
+                                                         layer.codebooks.dtype))
 
     def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         codebooks = layer.codebooks
