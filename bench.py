@@ -146,7 +146,8 @@ def timed_steps(runner, steps, warmup, dist_on):
 
 def time_dominant_kernel(stack, inputs, name, reps):
     """Average duration of one launch of the dominant linear's kernel: `reps` back-to-back launches over
-    the layers' distinct weights between two HIP events on the launch stream (no collectives)."""
+    the layers' distinct weights between two HIP events on the launch stream (no collectives); the median
+    of five such measurements."""
     layers = [b[name] for b in stack]
     x = inputs[name]
     qm = layers[0].quant_method
@@ -161,11 +162,14 @@ def time_dominant_kernel(stack, inputs, name, reps):
             qm.apply(layers[i % len(layers)], x)
     g.replay()
     torch.cuda.synchronize()
-    e0.record(stream)
-    g.replay()
-    e1.record(stream)
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / reps
+    per_launch = []
+    for _ in range(5):               # median of five replays: one replay of short launches is noisy
+        e0.record(stream)
+        g.replay()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        per_launch.append(e0.elapsed_time(e1) * 1e-3 / reps)
+    return sorted(per_launch)[len(per_launch) // 2]
 
 
 def cpu_baseline(T, dtype, budget_s=12.0, cap_s=30.0):

@@ -16,8 +16,8 @@
 // piece per lane holding the codes of that lane's KS k-steps, loaded once per chunk.
 //
 // Tile -> block map: blocks b and b+8 share an XCD (and its L2).  Each XCD takes a contiguous run of
-// (token tile, row tile) pairs in token-major order, so the blocks resident on one XCD read the same
-// activation tile from that XCD's L2 while each streams its own codes.
+// (token tile, row tile) pairs, ordered in groups of 4 token tiles x consecutive row tiles, so the blocks
+// resident on one XCD share a few activation tiles and a few row tiles' codes in that XCD's L2.
 #pragma once
 #include <stdlib.h>
 
@@ -54,6 +54,7 @@ __device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
 constexpr int TL_THREADS = 512;
 constexpr int TL_WAVES = 8;
 constexpr int TL_BK = 64;    // k per LDS tile
+constexpr int TL_GROUP_T = 4; // token tiles per group of the tile -> block map
 
 // byte offset of 16-byte slot `slot` (0..7) of row `row` inside a [rows][64] 16-bit tile
 __device__ inline uint32_t xt_off(int row, int slot) { return (uint32_t)row * 128u + (uint32_t)((slot ^ (row & 7)) << 4); }
@@ -116,8 +117,15 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     const int per_xcd = (total + 7) >> 3;
     const int pair = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (pair >= total) return;
-    const int t_tile = pair / n_tiles;
-    const TileLoc loc = locate_tile(tmap, pair - t_tile * n_tiles, BN);
+    // Within an XCD's run the pairs go in groups of TL_GROUP_T token tiles: GROUP_T token tiles of one row
+    // tile, then of the next row tile, ...  The ~32 blocks an XCD runs at a time then share 4 activation
+    // tiles and 8 row tiles' codes in its L2, instead of 1 and 32: fewer L2 misses for the same work.
+    const int gwidth = TL_GROUP_T * n_tiles;
+    const int gid = pair / gwidth, gin = pair - gid * gwidth;
+    const int gfirst = gid * TL_GROUP_T;
+    const int gsize = t_tiles - gfirst < TL_GROUP_T ? t_tiles - gfirst : TL_GROUP_T;
+    const int t_tile = gfirst + gin % gsize;
+    const TileLoc loc = locate_tile(tmap, gin / gsize, BN);
     const int t0 = t_tile * BT;
     const int row_end = loc.row0 + loc.nrows;
     const int Kin = G * D;
