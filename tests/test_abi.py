@@ -97,3 +97,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.PQLibraryError, match="no fallback"):
         _lib.load()
+
+
+def test_kernels_do_not_spill_registers():
+    """The MFMA kernels hold inline-asm loads in flight in registers the compiler does not track; a spill could save
+    such a register before its load has returned.  `make check-spills` compiles the kernel translation units to
+    assembly (cached under csrc/build) and fails on any non-zero spill count."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not (os.path.exists(hipcc) or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vllm_pq_amd", "csrc")
+    r = subprocess.run(["make", "-j4", "check-spills"], cwd=csrc, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "no register spills" in r.stdout

@@ -158,4 +158,18 @@ __device__ inline uint32_t code_index(CodeT c, uint32_t kmask) {
     return (uint32_t)(int32_t)c & kmask;
 }
 
+
+// Device-coherent 16-byte accesses (sc1: past the per-XCD L2, what a device-scope relaxed atomic access
+// compiles to) for data that blocks on different XCDs hand to each other inside one launch.  The load is only
+// issued: several can be in flight; `s_waitcnt vmcnt(0)` and coherent_landed() on each value come before use.
+__device__ __forceinline__ void coherent_store16(float *p, const f32x4 &v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 coherent_load16_issue(const float *p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void coherent_landed(f32x4 &v) { asm volatile("" : "+v"(v)); }
+
 }  // namespace pq

@@ -310,11 +310,7 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
             const int nb = loc.row0 + 16 * (fr / TF) + q * 4;
             if (t < T && nb < row_end) {
                 if (!split) finish(r, sum, t, nb);
-                else {
-                    float *pp = ws_part + ((size_t)zsplit * T + t) * (size_t)tmap.row_end[PQ_MAX_PARTS - 1] + nb;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) __hip_atomic_store(pp + e, sum[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                else coherent_store16(ws_part + ((size_t)zsplit * T + t) * (size_t)tmap.row_end[PQ_MAX_PARTS - 1] + nb, sum);
             }
         }
     }
@@ -344,12 +340,21 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
                     const int t = t0 + 16 * (fr % TF) + r16;
                     const int nb = loc.row0 + 16 * (fr / TF) + q * 4;
                     if (t < T && nb < row_end) {
-                        f32x4 sum{0.f, 0.f, 0.f, 0.f};
-                        for (int z = 0; z < ksplit; ++z) {
-                            const float *pp = ws_part + ((size_t)z * T + t) * n_total + nb;
+                        f32x4 part[8];   // all partials requested before any is waited for (ksplit <= 8)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                sum[e] += __hip_atomic_load(pp + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int z = 0; z < 8; ++z) {
+                            // no branch between issue and wait (a join could make the compiler copy a register whose load is
+                            // still in flight): splits past the last re-read the last one and are left out of the sum
+                            const int zc = z < ksplit ? z : ksplit - 1;
+                            part[z] = coherent_load16_issue(ws_part + ((size_t)zc * T + t) * n_total + nb);
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        f32x4 sum{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int z = 0; z < 8; ++z) coherent_landed(part[z]);
+#pragma unroll
+                        for (int z = 0; z < 8; ++z) {
+                            if (z < ksplit) { sum.x += part[z].x; sum.y += part[z].y; sum.z += part[z].z; sum.w += part[z].w; }
                         }
                         finish(r, sum, t, nb);
                     }
