@@ -112,3 +112,29 @@ def test_kernels_do_not_spill_registers():
     r = subprocess.run(["make", "-j4", "check-spills"], cwd=csrc, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "no register spills" in r.stdout
+    assert "in-flight lint: 0 violation(s)" in r.stdout
+
+
+def test_inflight_lint_catches_violations(tmp_path):
+    """The lint itself: reading, overwriting or branching with a hand-issued load in flight is reported; the same
+    code with the landing marker in place is clean."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lint_inflight", os.path.join(root, "tools", "lint_inflight.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    head = "kern:\n\t; PQI v5\n\tglobal_load_dword v5, v1, s[2:3]\n\t; PQI v[8:11]\n\tds_read_b128 v[8:11], v2 offset:16\n"
+    cases = {
+        "clean": head + "\tv_add_u32_e32 v3, v1, v2\n\ts_waitcnt vmcnt(0)\n\t; PQL v5\n\t; PQL v[8:11]\n\tv_mov_b32_e32 v6, v5\n\ts_endpgm\n",
+        "read": head + "\tv_mov_b32_e32 v6, v5\n\t; PQL v5\n\t; PQL v[8:11]\n\ts_endpgm\n",
+        "write": head + "\tv_mov_b32_e32 v9, v1\n\t; PQL v5\n\t; PQL v[8:11]\n\ts_endpgm\n",
+        "branch": head + "\ts_cbranch_scc1 .LBB0_1\n\t; PQL v5\n\t; PQL v[8:11]\n\ts_endpgm\n",
+        "never_landed": head + "\ts_endpgm\n",
+    }
+    got = {}
+    for name, text in cases.items():
+        f = tmp_path / (name + ".s")
+        f.write_text(text)
+        got[name] = lint.lint(str(f))
+    assert got["clean"] == 0
+    assert all(got[k] >= 1 for k in ("read", "write", "branch", "never_landed")), got

@@ -401,3 +401,20 @@ def test_k_split_default_on_long_k_layers(ops):
     tol = 0.51 * 2.0 ** -7 * ref.abs() + 1e-4 * rms
     assert ((y.float() - ref).abs() <= tol).all()
 
+
+
+@pytest.mark.parametrize("fmt", [(256, 8, 1), (256, 4, 1), (16, 2, 1), (4096, 8, 1), (4096, 4, 1), (256, 8, 2)])
+@pytest.mark.parametrize("cfg", range(7))
+def test_tiled_kernel_long_k_every_shape_and_format(ops, monkeypatch, fmt, cfg):
+    """Enough K for several trips round the main loop of every tile shape (10 to 40 loop steps: full unrolled
+    bodies, the back edge, and both tail lengths over the cases), for every code format."""
+    K, d, M = fmt
+    parts, Kin, T = [272, 144], 2560, 70
+    p = Problem(200 + cfg, K, d, M, parts, Kin, T, "fp16" if cfg % 2 else "bf16", bias=False).to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    assert packed is not None
+    monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "tiled")
+    monkeypatch.setenv("PQ_AMD_TILED_CFG", str(cfg))
+    y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(y), y32, "fp16" if cfg % 2 else "bf16", f"K={K} d={d} M={M} cfg {cfg}")

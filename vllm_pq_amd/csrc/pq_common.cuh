@@ -167,9 +167,9 @@ __device__ __forceinline__ void coherent_store16(float *p, const f32x4 &v) {
 }
 __device__ __forceinline__ f32x4 coherent_load16_issue(const float *p) {
     f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    asm volatile("; PQI %0\n\tglobal_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
-__device__ __forceinline__ void coherent_landed(f32x4 &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void coherent_landed(f32x4 &v) { asm volatile("; PQL %0" : "+v"(v)); }
 
 }  // namespace pq

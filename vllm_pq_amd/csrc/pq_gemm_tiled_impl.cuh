@@ -47,7 +47,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 template <int OFF>
 __device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
     u32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    asm volatile("; PQI %0\n\tds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
 
@@ -176,7 +176,10 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     // The PPU code pieces of loop step u, requested with inline-asm loads: the compiler neither moves
     // them across the DMA issue nor waits for them on its own (it drains vmcnt to 0 for any tracked load
     // that is pending together with an LDS-DMA), so the counted waits below are exact.  Until `landed`
-    // has been applied to a set after such a wait, its registers must not be read.
+    // has been applied to a set after such a wait, its registers must not be read -- by the compiler either:
+    // a register with a load in flight never lives across a branch, a join or a loop back edge (where a
+    // copy could be inserted); tools/lint_inflight.py checks the generated code for both ("; PQI" marks a
+    // hand-issued load or LDS read, "; PQL" the point from which its register may be read).
     auto load_pieces = [&](piece_t (&dst)[PPU][WN], int u) {
 #pragma unroll
         for (int pi = 0; pi < PPU; ++pi) {
@@ -188,10 +191,10 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
 #pragma unroll
                 for (int w = 0; w < PW; ++w) {
                     uint32_t t;
-                    if (w == 0) asm volatile("global_load_dword %0, %1, %2" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
-                    else if (w == 1) asm volatile("global_load_dword %0, %1, %2 offset:4" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
-                    else if (w == 2) asm volatile("global_load_dword %0, %1, %2 offset:8" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
-                    else asm volatile("global_load_dword %0, %1, %2 offset:12" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
+                    if (w == 0) asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
+                    else if (w == 1) asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2 offset:4" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
+                    else if (w == 2) asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2 offset:8" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
+                    else asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2 offset:12" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
                     dst[pi][i][w] = t;
                 }
             }
@@ -209,16 +212,27 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
 #pragma unroll
                 for (int w = 0; w < PW; ++w) {
                     uint32_t t = c[pi][i][w];
-                    asm volatile("" : "+v"(t));
+                    asm volatile("; PQL %0" : "+v"(t));
                     c[pi][i][w] = t;
                 }
             }
         }
     };
-    // the codes of the first two steps travel while the codebook image is built
+    // The codes of the first two steps travel while the codebook image is built (that code has loops): these
+    // are ordinary, compiler-tracked loads.
+    auto load_pieces_tracked = [&](piece_t (&dst)[PPU][WN], int u) {
+#pragma unroll
+        for (int pi = 0; pi < PPU; ++pi) {
+            const int p = u * PPU + pi;
+            const uint32_t off =
+                (uint32_t)(p / PIECES) * 1024u + (uint32_t)lane * 16u + (uint32_t)(p % PIECES) * (16u / PIECES);
+#pragma unroll
+            for (int i = 0; i < WN; ++i) dst[pi][i] = *reinterpret_cast<const piece_t *>(fbase[i] + off);
+        }
+    };
     piece_t c0[PPU][WN], c1[PPU][WN], c2[PPU][WN];
-    load_pieces(c0, 0);
-    load_pieces(c1, nsteps > 1 ? 1 : 0);
+    load_pieces_tracked(c0, 0);
+    load_pieces_tracked(c1, nsteps > 1 ? 1 : 0);
 
     // ---- codebook image ---------------------------------------------------------------------------
     {
@@ -261,7 +275,10 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     //   otherwise two sets: step u requests the codes of step u+1, which are older than the DMA issued in the
     //     step's last stage and so have landed after the step's last wait.
     int buf = 0, buf2 = 2;
-    auto step = [&](const piece_t (&cur)[PPU][WN], piece_t (&lands)[PPU][WN], piece_t (&req)[PPU][WN], int u) {
+    // `own` (DEEP only): the step also waits for its own request, so that no code load is in flight when it ends
+    // -- used for the last step before a loop back edge or a branch.
+    auto step = [&](const piece_t (&cur)[PPU][WN], piece_t (&lands)[PPU][WN], piece_t (&req)[PPU][WN], int u, auto own_c) {
+        constexpr bool own = decltype(own_c)::value;
         constexpr int AHEAD = DEEP ? 2 : 1;
         load_pieces(req, u + AHEAD < nsteps ? u + AHEAD : nsteps - 1);
 #pragma unroll
@@ -309,10 +326,10 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
                     };
                     constexpr bool halves = pp == 0 && kk > 0;   // this k-step's activations were requested in two
                                                                  // halves behind the previous group's MFMAs
-                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(P[c][0]), "+v"(P[c][1]) : "n"(newer + (halves ? H : 0)));
+                    asm volatile("s_waitcnt lgkmcnt(%2)\n\t; PQL %0\n\t; PQL %1" : "+v"(P[c][0]), "+v"(P[c][1]) : "n"(newer + (halves ? H : 0)));
                     if constexpr (pp == 0) {
 #pragma unroll
-                        for (int j = 0; j < (halves ? H : WT); ++j) asm volatile("" : "+v"(xfr[j]));
+                        for (int j = 0; j < (halves ? H : WT); ++j) asm volatile("; PQL %0" : "+v"(xfr[j]));
                     }
                     mfmas(0, H);
                     if constexpr (reload) {
@@ -324,7 +341,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
                         // newer than the second half: the next group's gathers and, if issued, the first half's re-reads
                         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(newer + (reload ? H : 0)));
 #pragma unroll
-                        for (int j = H; j < WT; ++j) asm volatile("" : "+v"(xfr[j]));
+                        for (int j = H; j < WT; ++j) asm volatile("; PQL %0" : "+v"(xfr[j]));
                     }
                     mfmas(H, WT);
                     if constexpr (reload) {
@@ -373,9 +390,9 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
 #pragma unroll
                     for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
-                        for (int j = 0; j < WT; ++j) asm volatile("" : "+v"(xr[slot][kb][j]));
+                        for (int j = 0; j < WT; ++j) asm volatile("; PQL %0" : "+v"(xr[slot][kb][j]));
 #pragma unroll
-                        for (int i = 0; i < WN; ++i) asm volatile("" : "+v"(ar[slot][kb][i]));
+                        for (int i = 0; i < WN; ++i) asm volatile("; PQL %0" : "+v"(ar[slot][kb][i]));
                     }
 #pragma unroll
                     for (int kb = 0; kb < NB; ++kb)
@@ -432,46 +449,48 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
             }
             if constexpr (!(ABL & 1)) {
                 // younger than the DMA of stage st+1: this stage's DMA and, in a step's first stage, its code loads
-                if (sg == 0 && (DEEP || SPU > 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KT * PPW + CL) : "memory");
+                if (sg == 0 && ((DEEP && !own) || SPU > 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KT * PPW + CL) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KT * PPW) : "memory");
-                if (sg == SPU - 1) landed(lands);
+                if (sg == SPU - 1) {
+                    landed(lands);
+                    if constexpr (DEEP && own) landed(req);
+                }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             } else {
                 if (sg == SPU - 1) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     landed(lands);
+                    if constexpr (DEEP && own) landed(req);
                 }
             }
             buf = buf == NBUF - 1 ? 0 : buf + 1;
             buf2 = buf2 == NBUF - 1 ? 0 : buf2 + 1;
         }
     };
+    constexpr std::integral_constant<bool, false> keep{};   // the request stays in flight into the next step
+    constexpr std::integral_constant<bool, true> land{};    // nothing in flight when the step ends
     if constexpr (DEEP) {
         int u = 0;
         for (; u + 3 <= nsteps; u += 3) {
-            step(c0, c1, c2, u);
-            step(c1, c2, c0, u + 1);
-            step(c2, c0, c1, u + 2);
+            step(c0, c1, c2, u, keep);
+            step(c1, c2, c0, u + 1, keep);
+            step(c2, c0, c1, u + 2, land);
         }
         if (u < nsteps) {
-            step(c0, c1, c2, u);
-            if (u + 1 < nsteps) step(c1, c2, c0, u + 1);
+            step(c0, c1, c2, u, land);
+            if (u + 1 < nsteps) step(c1, c2, c0, u + 1, land);
         }
     } else {
         int u = 0;
         for (; u + 2 <= nsteps; u += 2) {
-            step(c0, c1, c1, u);
-            step(c1, c0, c0, u + 1);
+            step(c0, c1, c1, u, land);
+            step(c1, c0, c0, u + 1, land);
         }
-        if (u < nsteps) step(c0, c1, c1, u);
+        if (u < nsteps) step(c0, c1, c1, u, land);
     }
-    // The last steps requested codes nobody reads: keep their registers reserved until those loads have
-    // returned, or a late return would overwrite whatever the epilogue keeps there.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    landed(c0);
-    landed(c1);
-    if constexpr (DEEP) landed(c2);
+    // every step above ended with its code loads landed; the activation DMA of the stages past the end may
+    // still be writing LDS, which nothing below reads
 
     // ---- epilogue: scale, bias, round, store ---------------------------------------------------------------
     // A lane holds 4 consecutive rows (8 bytes of y) of one token per fragment.  Fragments are taken in
@@ -595,10 +614,11 @@ static int tiled_step_tiles(const GemmArgs &a, int kt) {
     return kt > tpp ? kt : tpp;
 }
 
-// Shape i for this format.  With d = 2 a lane holds four times the codes per k-step, and the 256 x 256
-// shape would not fit the register file: its slot is a 256 x 128 tile with one k-tile per stage.
+// Shape i for this format.  With d = 2 (and d = 4 with two-byte codes) a lane holds more code registers per
+// k-step, and the 256 x 256 shape would not fit the register file: its slot is a 256 x 128 tile with one
+// k-tile per stage.
 static TiledCfg tiled_cfg(const GemmArgs &a, int i) {
-    if (i == 0 && a.d == 2) return TiledCfg{256, 128, 1};
+    if (i == 0 && (a.d == 2 || (a.d == 4 && a.code_bytes == 2))) return TiledCfg{256, 128, 1};
     // the 512 x 128 shape exists for d = 8, one codebook, one-byte codes; other formats run 256 x 128 in its slot
     if (i == 6 && !(a.d == 8 && a.M == 1 && a.code_bytes == 1)) return kTiledCfgs[1];
     return kTiledCfgs[i];
@@ -633,7 +653,7 @@ template <typename AT, typename CodeT, int D, int M>
 static hipError_t tiled_launch_fmt(const GemmArgs &a, hipStream_t stream) {
     switch (choose_tiled_cfg(a)) {
     case 0:
-        if constexpr (D == 2) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 1>(a, stream);   // 256 x 128
+        if constexpr (D == 2 || (D == 4 && sizeof(CodeT) == 2)) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 1>(a, stream);   // 256 x 128
         else return tiled_launch_cfg<AT, CodeT, D, M, 4, 8, 4, 1>(a, stream);                    // 256 x 256
     case 1: return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 2>(a, stream);   // 256 x 128
     case 2: return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 4, 2>(a, stream);   // 128 x 128
