@@ -21,6 +21,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <atomic>
+
 #include <type_traits>
 #include <utility>
 
@@ -584,12 +586,15 @@ static hipError_t tiled_launch_cfg(const GemmArgs &a, hipStream_t stream) {
     const int per_xcd = (total + 7) / 8;
     const size_t lds = (size_t)ST_MAX_LDS_CB + 3 * (size_t)KT * BT * TL_BK * 2;
     auto kern = gemm_tiled_kernel<AT, CodeT, D, M, WAVES_T, WN, WT, KT>;
-    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set) {
+    // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(TL_THREADS), lds, stream, static_cast<const uint16_t *>(a.x), a.T,
                        a.x_stride, static_cast<const u32x4 *>(a.codes), static_cast<const uint16_t *>(a.codebooks),
