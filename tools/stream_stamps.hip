@@ -53,11 +53,10 @@ void run(const char *label, int T, int N, int G, int nparts) {
     CK(hipFree(x)); CK(hipFree(cb)); CK(hipFree(sc)); CK(hipFree(y)); CK(hipFree(st));
 }
 int main() {
-    run<8, 1>("gate_up", 1, 28672, 512, 2);
-    run<8, 1>("gate_up", 16, 28672, 512, 2);
-    run<1, 1>("o_proj", 1, 4096, 512, 1);
-    run<1, 1>("down", 1, 4096, 1792, 1);
+    run<1, 1>("o_proj", 16, 4096, 512, 1);
     run<4, 2>("o_proj", 32, 4096, 512, 1);
-    run<4, 4>("o_proj", 256, 4096, 512, 1);
+    run<4, 2>("gate_up", 32, 28672, 512, 2);
+    run<8, 1>("gate_up", 16, 28672, 512, 2);
+    run<4, 4>("o_proj", 128, 4096, 512, 1);
     return 0;
 }

@@ -50,6 +50,8 @@ def point(w, name, parts, kin, K, d, T, dt, reps, budget_bytes):
             w["sets"].append((codes, cbk, sc, ops.pq_repack_codes(codes, cbk, parts)))
     sets = w["sets"]
     x = torch.randn(T, kin, device=dev).to(dt)
+    # the scratch a loaded layer has (process_weights_after_loading sizes it the same way)
+    ops.ensure_workspace(torch.device(dev, torch.cuda.current_device()), ops.workspace_bytes(128, N, G, 1, K, d, cb, dt))
 
     def call(s):
         if s[3] is not None:

@@ -66,6 +66,19 @@ static double stream_model_us(const GemmArgs &a, int nf, int tf, int ksplit) {
     return rounds * (4.0 + (ksplit > 1 ? 2.0 : 0.0) + per_wave * (ks / subk) * 1.9);   // + 2 us: partial sums, count, re-read
 }
 
+// The same for blocks of one token fragment (TF = 1) and NF weight fragments: 5.3 us fixed, and per chunk
+// of a wave 1 us for its activations plus 0.5 us per weight fragment gathered (a chunk of 16 k-steps;
+// shorter chunks in proportion).  Measured at 32 <= T <= 128 on 4096 x 4096 ... 4096 x 14336 layers.
+static double stream_tall_model_us(const GemmArgs &a, int nf, int ksplit) {
+    const int cg = chunk_groups(a.code_bytes, a.M);
+    const int ks = (cg / 4) * a.d / 8;
+    const double nchunks = (double)((a.G + cg - 1) / cg) / ksplit;
+    const long blocks = (long)tiles_in(a.parts, nf * 16) * ((a.T + 15) / 16) * ksplit;
+    const double rounds = (double)((blocks + 255) / 256);
+    const double per_wave = nchunks / 8.0 < 1.0 ? 1.0 : nchunks / 8.0;
+    return rounds * (5.3 + (ksplit > 1 ? 2.0 : 0.0) + per_wave * (ks / 16.0) * (1.0 + 0.5 * nf));
+}
+
 // ---- K split over blocks ---------------------------------------------------------------------------
 // Decode batches on a layer with few rows and a long K (down_proj: 4096 x 14336) leave two bad choices
 // without it: 16-row tiles (one block per CU, but every block then reads all of x -- 16 x the bytes of its
@@ -152,6 +165,19 @@ StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {
             const int ks = split_for(c.nf, c.tf, forced ? forced : want);
             const double us = stream_model_us(a, c.nf, c.tf, ks);
             if (best_us < 0.0 || us < best_us) { best_us = us; best = StreamCfg{c.nf, c.tf, ks}; }
+        }
+    }
+    // ... or one token fragment per block and the batch spread over grid.y: every block then loads only 16
+    // tokens of x (a wide block's waves spend most of their time loading theirs), at the price of gathering
+    // each weight fragment once per 16 tokens.  Pays while the whole grid still fits the chip in one round.
+    static const int tall[] = {8, 7, 4, 2, 1};
+    for (int nf : tall) {
+        if (nf > 2 && !light) continue;
+        for (int want = 1; want <= smax; want *= 2) {
+            if (forced && want != 1) continue;
+            const int ks = split_for(nf, 1, forced ? forced : want);
+            const double us = stream_tall_model_us(a, nf, ks);
+            if (us < best_us) { best_us = us; best = StreamCfg{nf, 1, ks}; }
         }
     }
     if (model_us) *model_us = best_us;
