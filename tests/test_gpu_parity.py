@@ -301,7 +301,8 @@ def test_tiled_kernel_other_formats_tile_shapes(ops, monkeypatch, fmt, cfg):
 
 
 @pytest.mark.parametrize("cfg,T", [("1x1", 3), ("2x1", 16), ("4x1", 9), ("7x1", 16), ("8x1", 1), ("4x2", 30),
-                                   ("4x2", 70), ("2x4", 64), ("4x4", 100)])
+                                   ("4x2", 70), ("2x4", 64), ("4x4", 100), ("7x2", 32), ("7x2", 50),
+                                   ("8x1", 64), ("2x1", 40)])
 def test_stream_kernel_every_tile_shape(ops, monkeypatch, cfg, T):
     """K spans 2.5 chunks per wave set (ragged last chunk), rows leave partial tiles for every NF."""
     parts, Kin = [400, 176], 1280

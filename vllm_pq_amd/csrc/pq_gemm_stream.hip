@@ -63,7 +63,8 @@ static double stream_model_us(const GemmArgs &a, int nf, int tf, int ksplit) {
     const double rounds = (double)((blocks + 255) / 256);
     const double per_wave = nchunks / 8.0 < 1.0 ? 1.0 : nchunks / 8.0;
     const int subk = 8 / tf < ks ? 8 / tf : ks;
-    return rounds * (4.0 + (ksplit > 1 ? 2.0 : 0.0) + per_wave * (ks / subk) * 1.9);   // + 2 us: partial sums, count, re-read
+    const double tall = nf > 4 ? 1.3 * (nf - 4) : 0.0;   // gathers of the fragments beyond four, per chunk
+    return rounds * (4.0 + (ksplit > 1 ? 2.0 : 0.0) + per_wave * ((ks / subk) * 1.9 + tall));   // + 2 us: partial sums, count, re-read
 }
 
 // The same for blocks of one token fragment (TF = 1) and NF weight fragments: 5.3 us fixed, and per chunk
@@ -131,7 +132,8 @@ StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {
         int nf = 0, tf = 0;
         if (sscanf(env, "%dx%d", &nf, &tf) == 2) {
             const bool ok1 = tf == 1 && (nf == 1 || nf == 2 || (light && (nf == 4 || (packed && (nf == 7 || nf == 8)))));
-            const bool okw = packed && ((nf == 4 && tf == 4 && light) || (nf == 4 && tf == 2) || (nf == 2 && tf == 4));
+            const bool okw = packed && ((nf == 4 && tf == 4 && light) || (nf == 4 && tf == 2) || (nf == 2 && tf == 4) ||
+                                        (nf == 7 && tf == 2 && light));
             if (ok1 || okw) return StreamCfg{nf, tf, split_for(nf, tf, forced ? forced : 1)};
         }
     }
@@ -154,11 +156,11 @@ StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {
         return best;
     }
     // 17 tokens and more: the shape and split with the shortest modelled launch
-    static const StreamCfg wide[] = {{4, 4, 1}, {2, 4, 1}, {4, 2, 1}};
+    static const StreamCfg wide[] = {{4, 4, 1}, {2, 4, 1}, {4, 2, 1}, {7, 2, 1}};
     StreamCfg best = wide[2];
     double best_us = -1.0;
     for (const StreamCfg &c : wide) {
-        if (c.nf == 4 && c.tf == 4 && !light) continue;
+        if (c.nf * c.tf > 8 && !light) continue;
         if (c.tf == 4 && a.T <= 32) continue;   // half the token tile would be padding
         for (int want = 1; want <= smax; want *= 2) {
             if (forced && want != 1) continue;

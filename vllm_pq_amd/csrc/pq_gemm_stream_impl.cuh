@@ -39,6 +39,8 @@ namespace pq {
 
 constexpr int ST_THREADS = 512;
 constexpr int ST_WAVES = ST_THREADS / 64;
+// accumulator fragments summed across the waves per round: the largest divisor of the tile's count up to 8
+constexpr int stream_reduce_frags(int fr) { return fr <= 8 ? fr : fr % 8 == 0 ? 8 : fr % 7 == 0 ? 7 : fr % 6 == 0 ? 6 : 4; }
 
 // ABL (diagnostic builds only; 0 in the library): bit 0 skips the LDS gather, bit 1 the MFMAs, bit 2 the
 // code loads, bit 3 the activation loads, bit 4 the codebook image, bit 5 the cross-wave sum + stores.
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
     constexpr int SUBK = (8 / TF) < KS ? (8 / TF) : KS;   // k-steps per activation sub-load: <= 32 registers
     constexpr int NSUB = KS / SUBK;
     constexpr int FR = NF * TF;                            // accumulator fragments per wave
-    constexpr int RF = FR < 8 ? FR : 8;                    // fragments per reduction round (<= 64 KiB of LDS)
+    constexpr int RF = stream_reduce_frags(FR);            // fragments per reduction round (<= 64 KiB of LDS)
     constexpr int ROUNDS = FR / RF;
     static_assert(KS % SUBK == 0 && FR % RF == 0, "unsupported tile shape");
 
@@ -373,7 +375,7 @@ template <typename AT, typename CodeT, int D, int M, int NF, int TF, bool PACKED
 static hipError_t launch_nf(const GemmArgs &a, int ksplit, hipStream_t stream) {
     const int R = stream_replication<D>(a.K, a.M);
     const int nbits = __builtin_ctz((unsigned)a.K);
-    constexpr int RF = NF * TF < 8 ? NF * TF : 8;
+    constexpr int RF = stream_reduce_frags(NF * TF);
     size_t lds = (size_t)a.M * a.K * 2 * D * R;
     const size_t red = (size_t)ST_WAVES * RF * 64 * 16;
     if (red > lds) lds = red;
@@ -399,7 +401,11 @@ static hipError_t launch_fmt(const GemmArgs &a, hipStream_t stream) {
                 if (c.nf == 4) return launch_nf<AT, CodeT, D, M, 4, 4, true>(a, c.ksplit, stream);
             return launch_nf<AT, CodeT, D, M, 2, 4, true>(a, c.ksplit, stream);
         }
-        if (c.tf == 2) return launch_nf<AT, CodeT, D, M, 4, 2, true>(a, c.ksplit, stream);
+        if (c.tf == 2) {
+            if constexpr (LIGHT)
+                if (c.nf == 7) return launch_nf<AT, CodeT, D, M, 7, 2, true>(a, c.ksplit, stream);
+            return launch_nf<AT, CodeT, D, M, 4, 2, true>(a, c.ksplit, stream);
+        }
         if constexpr (LIGHT) {
             switch (c.nf) {
             case 8: return launch_nf<AT, CodeT, D, M, 8, 1, true>(a, c.ksplit, stream);
