@@ -210,6 +210,48 @@ def cpu_baseline(T, dtype, budget_s=12.0, cap_s=30.0):
                       f"generic_dequantize_gemm"}
 
 
+def time_neighbours(T, device, dtype, world, cfg=LLAMA3_8B, reps=5):
+    """The element-wise kernels either side of the linears (silu_and_mul after gate_up_proj, fused_add_rms_norm
+    before qkv_proj / gate_up_proj) at this token count: achieved HBM GB/s on their algorithmic bytes, timed
+    with events around a HIP-graph replay of back-to-back launches over rotating buffers."""
+    from vllm_pq_amd import ops
+    inter, hidden = cfg["inter"] // world, cfg["hidden"]
+    out = {}
+
+    def timed(fn, sets, nbytes):
+        fn(sets[0])
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for s_ in sets:
+                fn(s_)
+        g.replay()
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e-3 / len(sets))
+        return {"launch_us": best * 1e6, "algorithmic_bytes": nbytes, "achieved": nbytes / best / 1e9,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / best / 1e9 / HBM_PEAK_GBPS}
+
+    n_sets = max(2, min(8, int(600e6 / max(1, T * inter * 6)) + 1))
+    sets = [(torch.randn(T, 2 * inter, device=device).to(dtype), torch.empty(T, inter, device=device, dtype=dtype))
+            for _ in range(n_sets)]
+    out["silu_and_mul"] = timed(lambda s_: ops.silu_and_mul(s_[1], s_[0]), sets, T * inter * 2 * 3)
+    del sets
+    n_sets = max(2, min(16, int(600e6 / max(1, T * hidden * 8)) + 1))
+    w = torch.ones(hidden, device=device, dtype=dtype)
+    sets = [(torch.randn(T, hidden, device=device).to(dtype), torch.randn(T, hidden, device=device).to(dtype))
+            for _ in range(n_sets)]
+    out["fused_add_rms_norm"] = timed(lambda s_: ops.fused_add_rms_norm(s_[0], s_[1], w, 1e-5), sets,
+                                      T * hidden * 2 * 4 + hidden * 2)
+    return out
+
+
 def profiled_traffic(key):
     """HBM bytes per launch of a kernel as measured by the committed rocprofv3 counter passes
     (profiles/traffic_r*.json, newest round first); None when that launch was not profiled."""
@@ -253,6 +295,7 @@ def main():
                          "by default multi-GPU steps are launched eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-neighbours", action="store_true", help="skip the element-wise kernels' measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -324,6 +367,12 @@ def main():
                                                               dom_parts, packed=dom_packed) + ":" + dom,
                                "launch_us": t_kd * 1e6}}
 
+    neighbours = None
+    if not args.no_neighbours:
+        neighbours = {f"T{T}": time_neighbours(T, device, dtype, world)}
+        if not args.no_decode and args.decode_tokens != T:
+            neighbours[f"T{args.decode_tokens}"] = time_neighbours(args.decode_tokens, device, dtype, world)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(T, dtype)
@@ -339,7 +388,7 @@ def main():
                        "tokens_per_step": T, "parallelism": f"tp{world}", "launch": main_m["launch"],
                        "apply_calls_per_step": 4 * len(stack)},
             "hbm_gbps": main_m["gbps"], "tokens_per_s": main_m["tokens_per_s"],
-            "roofline": roof, "cpu_baseline": cpu, "decode": decode,
+            "roofline": roof, "cpu_baseline": cpu, "decode": decode, "neighbours": neighbours,
         }
         print(json.dumps(line), flush=True)
     if dist_on:

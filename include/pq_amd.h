@@ -63,6 +63,7 @@ typedef enum pq_status {
 #define PQ_CAP_MFMA_TILED (1ull << 3)   /* fused gather+MFMA tiled kernel (prefill)   */
 #define PQ_CAP_BF16 (1ull << 4)
 #define PQ_CAP_FP16 (1ull << 5)
+#define PQ_CAP_ELEMENTWISE (1ull << 6) /* pq_silu_and_mul, pq_rms_norm, pq_fused_add_rms_norm */
 
 /* Version of this ABI (PQ_ABI_VERSION) and capability bits.  No reference counterpart. */
 int pq_version(void);
@@ -139,6 +140,31 @@ int pq_gemm_packed(const void *x, int32_t T, int64_t x_row_stride, const void *p
 int pq_gemm_kernel_name(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes,
                         int32_t dtype, const int32_t *part_sizes, int32_t num_parts, int32_t packed, char *buf,
                         size_t buf_len);
+
+/*
+ * The element-wise steps either side of the PQ linears in a decoder layer (vllm/model_executor/models/llama.py:
+ * 89-93 act_fn after gate_up_proj, :272-284 the two norms before qkv_proj and gate_up_proj).  Rows are
+ * row-stride elements apart; 16-byte aligned pointers and strides with a row length that is a multiple of 8
+ * take the vectorised kernels, anything else a slower element-wise one.
+ *
+ * pq_silu_and_mul: out[t][j] = silu(x[t][j]) * x[t][I + j], x [T][2 I], out [T][I].  Replaces
+ *   silu_and_mul(Tensor! out, Tensor input) (csrc/torch_bindings.cpp:55-56, csrc/activation_kernels.cu:22-38,
+ *   :82-86); numerically SiluAndMul.forward_native (vllm/model_executor/layers/activation.py:73-76): silu in fp32
+ *   rounded to the act dtype, the product rounded once more.
+ * pq_rms_norm: out[t][:] = round(x[t][:] * rsqrt(mean(x[t]^2) + eps)) * weight, statistics in fp32.  Replaces
+ *   rms_norm(Tensor! result, Tensor input, Tensor weight, float epsilon) (csrc/torch_bindings.cpp:106-109,
+ *   csrc/layernorm_kernels.cu:17-44); numerically RMSNorm.forward_native (layers/layernorm.py:38-74).
+ * pq_fused_add_rms_norm: z = x + residual in fp32; residual <- round(z); x <- the norm of z, both in place.
+ *   Replaces fused_add_rms_norm(Tensor! input, Tensor! residual, Tensor weight, float epsilon)
+ *   (csrc/torch_bindings.cpp:112-115, csrc/layernorm_kernels.cu:50-100).  The variance uses the unrounded sum, as
+ *   forward_native does (layernorm.py:45-48, :65); the reference's CUDA kernel uses the rounded one.
+ */
+int pq_silu_and_mul(const void *x, int64_t x_row_stride, int32_t T, int32_t I, int32_t dtype, void *out,
+                    int64_t out_row_stride, void *stream);
+int pq_rms_norm(const void *x, int64_t x_row_stride, const void *weight, float eps, int32_t T, int32_t H,
+                int32_t dtype, void *out, int64_t out_row_stride, void *stream);
+int pq_fused_add_rms_norm(void *x, int64_t x_row_stride, void *residual, int64_t res_row_stride, const void *weight,
+                          float eps, int32_t T, int32_t H, int32_t dtype, void *stream);
 
 #ifdef __cplusplus
 }

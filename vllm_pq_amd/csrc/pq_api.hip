@@ -93,7 +93,8 @@ extern "C" {
 int pq_version(void) { return PQ_ABI_VERSION; }
 
 uint64_t pq_caps(void) {
-    return PQ_CAP_DEQUANT | PQ_CAP_GEMM | PQ_CAP_MFMA_SMALL_T | PQ_CAP_MFMA_TILED | PQ_CAP_BF16 | PQ_CAP_FP16;
+    return PQ_CAP_DEQUANT | PQ_CAP_GEMM | PQ_CAP_MFMA_SMALL_T | PQ_CAP_MFMA_TILED | PQ_CAP_BF16 | PQ_CAP_FP16 |
+           PQ_CAP_ELEMENTWISE;
 }
 
 const char *pq_last_error(void) { return g_err; }
@@ -226,6 +227,59 @@ int pq_gemm_kernel_name(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, i
     static const char *names[] = {"generic", "mfma_stream", "mfma_tiled"};
     snprintf(buf, buf_len, "%s%s", names[choose(a)], a.packed ? "_packed" : "");
     return PQ_OK;
+}
+
+// ---- element-wise neighbours ---------------------------------------------------------------------
+static int check_rows(const char *fn, int32_t T, int32_t H, int32_t dtype) {
+    if (T < 0 || H < 0) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: bad shape T=%d H=%d", fn, T, H);
+    if (dtype != PQ_DTYPE_FP16 && dtype != PQ_DTYPE_BF16)
+        return fail(PQ_ERR_INVALID_ARGUMENT, "%s: dtype=%d is neither fp16 (0) nor bf16 (1)", fn, dtype);
+    return PQ_OK;
+}
+
+int pq_silu_and_mul(const void *x, int64_t x_row_stride, int32_t T, int32_t I, int32_t dtype, void *out,
+                    int64_t out_row_stride, void *stream) {
+    int rc = check_rows("pq_silu_and_mul", T, I, dtype);
+    if (rc) return rc;
+    if (T == 0 || I == 0) return PQ_OK;
+    if (!x || !out) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_silu_and_mul: NULL tensor pointer");
+    if (x_row_stride < 2 * (int64_t)I || out_row_stride < I)
+        return fail(PQ_ERR_INVALID_ARGUMENT, "pq_silu_and_mul: row strides %lld / %lld shorter than the rows (2*%d / %d)",
+                    (long long)x_row_stride, (long long)out_row_stride, I, I);
+    pq::ElementwiseArgs a{x, x_row_stride, nullptr, 0, nullptr, 0.f, T, I, dtype, out, out_row_stride};
+    hipError_t e = pq::launch_silu_and_mul(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "pq_silu_and_mul: %s", hipGetErrorString(e));
+    return PQ_OK;
+}
+
+static int rms_common(const char *fn, const void *x, int64_t x_row_stride, void *residual, int64_t res_row_stride,
+                      const void *weight, float eps, int32_t T, int32_t H, int32_t dtype, void *out,
+                      int64_t out_row_stride, void *stream) {
+    int rc = check_rows(fn, T, H, dtype);
+    if (rc) return rc;
+    if (T == 0 || H == 0) return PQ_OK;
+    if (!x || !out || !weight) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: NULL tensor pointer", fn);
+    if (x_row_stride < H || out_row_stride < H || (residual && res_row_stride < H))
+        return fail(PQ_ERR_INVALID_ARGUMENT, "%s: a row stride is shorter than the row (%d)", fn, H);
+    pq::ElementwiseArgs a{x, x_row_stride, residual, res_row_stride, weight, eps, T, H, dtype, out, out_row_stride};
+    if (!pq::rms_norm_vectorised(a) && H > pq::RMS_SCALAR_MAX_H)
+        return fail(PQ_ERR_UNSUPPORTED, "%s: rows of %d elements need 16-byte aligned tensors, strides and H %% 8 == 0 "
+                    "(up to 16384 elements); unaligned rows are supported up to %d", fn, H, pq::RMS_SCALAR_MAX_H);
+    hipError_t e = pq::launch_rms_norm(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "%s: %s", fn, hipGetErrorString(e));
+    return PQ_OK;
+}
+
+int pq_rms_norm(const void *x, int64_t x_row_stride, const void *weight, float eps, int32_t T, int32_t H,
+                int32_t dtype, void *out, int64_t out_row_stride, void *stream) {
+    return rms_common("pq_rms_norm", x, x_row_stride, nullptr, 0, weight, eps, T, H, dtype, out, out_row_stride, stream);
+}
+
+int pq_fused_add_rms_norm(void *x, int64_t x_row_stride, void *residual, int64_t res_row_stride, const void *weight,
+                          float eps, int32_t T, int32_t H, int32_t dtype, void *stream) {
+    if (T > 0 && H > 0 && !residual) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_fused_add_rms_norm: residual is NULL");
+    return rms_common("pq_fused_add_rms_norm", x, x_row_stride, residual, res_row_stride, weight, eps, T, H, dtype, x,
+                      x_row_stride, stream);
 }
 
 }  // extern "C"

@@ -67,4 +67,22 @@ hipError_t launch_repack(const void *codes, int N, int G, int M, int d, int code
 bool gemm_tiled_supported(const GemmArgs &a);
 hipError_t launch_gemm_tiled(const GemmArgs &a, hipStream_t stream);
 
+// The element-wise neighbours of the linears (pq_elementwise.hip).  H = row length (for silu_and_mul: the
+// output's, the input row holds 2 H); residual != NULL selects the fused add.
+struct ElementwiseArgs {
+    const void *x;
+    int64_t x_stride;
+    void *residual;
+    int64_t res_stride;
+    const void *weight;
+    float eps;
+    int T, H, dtype;
+    void *out;
+    int64_t out_stride;
+};
+constexpr int RMS_SCALAR_MAX_H = 15360;   // rows the unaligned fallback holds in LDS as fp32
+bool rms_norm_vectorised(const ElementwiseArgs &a);
+hipError_t launch_silu_and_mul(const ElementwiseArgs &a, hipStream_t stream);
+hipError_t launch_rms_norm(const ElementwiseArgs &a, hipStream_t stream);
+
 }  // namespace pq

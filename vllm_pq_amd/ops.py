@@ -244,6 +244,110 @@ def pq_dequant(codes: torch.Tensor, codebooks: torch.Tensor, codebook_partition_
     return _pq_dequant_impl(codes, codebooks, codebook_partition_sizes, scales)
 
 
+# ---- the element-wise neighbours of the linears -------------------------------------------------
+# Same names, argument order and in-place conventions as the reference's wrappers
+# (vllm/_custom_ops.py:151-158 rms_norm / fused_add_rms_norm; torch.ops._C.silu_and_mul as called from
+# vllm/model_executor/layers/activation.py:78-83).
+def _rows(t: torch.Tensor, what: str):
+    """(2-D view sharing t's memory, row stride); raises when t cannot be addressed as strided rows."""
+    if t.dim() < 1 or t.stride(-1) != 1:
+        raise ValueError(f"{what}: the last dimension must be contiguous")
+    t2 = t.reshape(-1, t.shape[-1]) if t.dim() != 2 else t
+    if t2.data_ptr() != t.data_ptr():
+        raise ValueError(f"{what}: leading dimensions cannot be flattened without a copy")
+    return t2, (t2.stride(0) if t2.shape[0] > 1 else t2.shape[1])
+
+
+def _silu_and_mul_impl(out: torch.Tensor, input: torch.Tensor) -> None:
+    L = _lib.load()
+    dev = _check_device(out, input)
+    if input.dtype not in _DTYPE or out.dtype != input.dtype:
+        raise ValueError(f"silu_and_mul: fp16 / bf16 tensors of one dtype expected, got {input.dtype} -> {out.dtype}")
+    I = input.shape[-1] // 2
+    if input.shape[-1] != 2 * I or out.shape != input.shape[:-1] + (I,):
+        raise ValueError(f"silu_and_mul: input {tuple(input.shape)} does not halve into out {tuple(out.shape)}")
+    x2, xs = _rows(input, "silu_and_mul input")
+    o2, os_ = _rows(out, "silu_and_mul out")
+    with torch.cuda.device(dev):
+        rc = L.pq_silu_and_mul(x2.data_ptr(), max(xs, 2 * I), x2.shape[0], I, _DTYPE[input.dtype], o2.data_ptr(),
+                               max(os_, I), _stream_ptr(dev))
+    if rc:
+        _raise(rc)
+
+
+def _rms_norm_impl(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor, epsilon: float) -> None:
+    L = _lib.load()
+    dev = _check_device(out, input, weight)
+    H = input.shape[-1]
+    if input.dtype not in _DTYPE or out.dtype != input.dtype or weight.dtype != input.dtype:
+        raise ValueError("rms_norm: input, out and weight must share one of fp16 / bf16")
+    if out.shape != input.shape or weight.shape != (H,):
+        raise ValueError(f"rms_norm: shapes {tuple(input.shape)} -> {tuple(out.shape)}, weight {tuple(weight.shape)}")
+    x2, xs = _rows(input, "rms_norm input")
+    o2, os_ = _rows(out, "rms_norm out")
+    with torch.cuda.device(dev):
+        rc = L.pq_rms_norm(x2.data_ptr(), xs, weight.contiguous().data_ptr(), float(epsilon), x2.shape[0], H,
+                           _DTYPE[input.dtype], o2.data_ptr(), os_, _stream_ptr(dev))
+    if rc:
+        _raise(rc)
+
+
+def _fused_add_rms_norm_impl(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                             epsilon: float) -> None:
+    L = _lib.load()
+    dev = _check_device(input, residual, weight)
+    H = input.shape[-1]
+    if input.dtype not in _DTYPE or residual.dtype != input.dtype or weight.dtype != input.dtype:
+        raise ValueError("fused_add_rms_norm: input, residual and weight must share one of fp16 / bf16")
+    if residual.shape != input.shape or weight.shape != (H,):
+        raise ValueError(f"fused_add_rms_norm: shapes {tuple(input.shape)} / {tuple(residual.shape)}, "
+                         f"weight {tuple(weight.shape)}")
+    x2, xs = _rows(input, "fused_add_rms_norm input")
+    r2, rs = _rows(residual, "fused_add_rms_norm residual")
+    with torch.cuda.device(dev):
+        rc = L.pq_fused_add_rms_norm(x2.data_ptr(), xs, r2.data_ptr(), rs, weight.contiguous().data_ptr(),
+                                     float(epsilon), x2.shape[0], H, _DTYPE[input.dtype], _stream_ptr(dev))
+    if rc:
+        _raise(rc)
+
+
+if _HAVE_CUSTOM_OP:
+
+    @torch.library.custom_op("pq_amd::silu_and_mul", mutates_args=("out",), device_types="cuda")
+    def _silu_and_mul_op(out: torch.Tensor, input: torch.Tensor) -> None:
+        _silu_and_mul_impl(out, input)
+
+    @torch.library.custom_op("pq_amd::rms_norm", mutates_args=("out",), device_types="cuda")
+    def _rms_norm_op(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor, epsilon: float) -> None:
+        _rms_norm_impl(out, input, weight, epsilon)
+
+    @torch.library.custom_op("pq_amd::fused_add_rms_norm", mutates_args=("input", "residual"), device_types="cuda")
+    def _fused_add_rms_norm_op(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                               epsilon: float) -> None:
+        _fused_add_rms_norm_impl(input, residual, weight, epsilon)
+
+
+def silu_and_mul(out: torch.Tensor, input: torch.Tensor) -> None:
+    """out[..., j] = silu(input[..., j]) * input[..., I + j]; `out` is written in place."""
+    if _HAVE_CUSTOM_OP and input.is_cuda and out.is_cuda:
+        return torch.ops.pq_amd.silu_and_mul(out, input)
+    _silu_and_mul_impl(out, input)
+
+
+def rms_norm(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor, epsilon: float) -> None:
+    """out = RMS-normalised input times weight (vllm/_custom_ops.py:151-153)."""
+    if _HAVE_CUSTOM_OP and input.is_cuda and out.is_cuda:
+        return torch.ops.pq_amd.rms_norm(out, input, weight, float(epsilon))
+    _rms_norm_impl(out, input, weight, epsilon)
+
+
+def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, epsilon: float) -> None:
+    """residual += input; input = RMS-norm(residual) * weight, both in place (vllm/_custom_ops.py:156-158)."""
+    if _HAVE_CUSTOM_OP and input.is_cuda and residual.is_cuda:
+        return torch.ops.pq_amd.fused_add_rms_norm(input, residual, weight, float(epsilon))
+    _fused_add_rms_norm_impl(input, residual, weight, epsilon)
+
+
 def gemm_kernel_name(T: int, N: int, G: int, M: int, K: int, d: int, code_bytes: int, dtype: torch.dtype,
                      partition_sizes, packed: bool = False) -> str:
     """Name of the kernel pq_gemm selects for a problem (no GPU needed)."""
