@@ -64,12 +64,14 @@ static double stream_model_us(const GemmArgs &a, int nf, int tf, int ksplit) {
     const double per_wave = nchunks / 8.0 < 1.0 ? 1.0 : nchunks / 8.0;
     const int subk = 8 / tf < ks ? 8 / tf : ks;
     const double tall = nf > 4 ? 1.3 * (nf - 4) : 0.0;   // gathers of the fragments beyond four, per chunk
-    return rounds * (4.0 + (ksplit > 1 ? 2.0 : 0.0) + per_wave * ((ks / subk) * 1.9 + tall));   // + 2 us: partial sums, count, re-read
+    const double fixed = stream_light_format(a) ? 4.0 : 7.0;   // measured: 3 us more for d < 8, two-byte codes, M = 2
+    return rounds * (fixed + (ksplit > 1 ? 2.0 : 0.0) + per_wave * ((ks / subk) * 1.9 + tall));   // + 2 us: partial sums, count, re-read
 }
 
-// The same for blocks of one token fragment (TF = 1) and NF weight fragments: 5.3 us fixed, and per chunk
-// of a wave 1 us for its activations plus 0.5 us per weight fragment gathered (a chunk of 16 k-steps;
-// shorter chunks in proportion).  Measured at 32 <= T <= 128 on 4096 x 4096 ... 4096 x 14336 layers.
+// The same for blocks of one token fragment (TF = 1) and NF weight fragments: 5.3 us fixed; a wave's first
+// chunk costs 1 us for its activations plus 0.5 us per weight fragment gathered (a chunk of 16 k-steps;
+// shorter chunks in proportion), every further chunk of the wave 1.55 us per activation sub-load (round trips
+// that nothing overlaps) + 0.2 us per fragment.  Measured at 4 <= T <= 128 on 4096 x 4096 ... 8192 x 8192 layers.
 static double stream_tall_model_us(const GemmArgs &a, int nf, int ksplit) {
     const int cg = chunk_groups(a.code_bytes, a.M);
     const int ks = (cg / 4) * a.d / 8;
@@ -77,7 +79,10 @@ static double stream_tall_model_us(const GemmArgs &a, int nf, int ksplit) {
     const long blocks = (long)tiles_in(a.parts, nf * 16) * ((a.T + 15) / 16) * ksplit;
     const double rounds = (double)((blocks + 255) / 256);
     const double per_wave = nchunks / 8.0 < 1.0 ? 1.0 : nchunks / 8.0;
-    return rounds * (5.3 + (ksplit > 1 ? 2.0 : 0.0) + per_wave * (ks / 16.0) * (1.0 + 0.5 * nf));
+    const int nsub = ks > 8 ? ks / 8 : 1;   // sub-loads per chunk at TF = 1
+    const double scale = ks / 16.0;
+    const double chunks_us = scale * (1.0 + 0.5 * nf) + (per_wave - 1.0) * (1.55 * nsub + scale * 0.2 * nf);
+    return rounds * (5.3 + (ksplit > 1 ? 2.0 : 0.0) + chunks_us);
 }
 
 // ---- K split over blocks ---------------------------------------------------------------------------
@@ -138,20 +143,21 @@ StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {
         }
     }
     if (!packed || a.T <= 16) {
-        // One token fragment.  Measured on the MI355X (T = 16, K = 4096): a launch whose blocks fit one round
-        // (one block per CU) lasts about 6.3 us + 0.5 us per weight fragment of the tile, and blocks beyond
-        // 256 add time in proportion -- so prefer the shape whose grid just fits the chip.  From 4 tokens on
-        // a long K is split over blocks when it can be: each block then reads only its slice of x.
+        // One token fragment: the shape and K split with the shortest modelled launch.  In short: a grid that
+        // just fits the chip in one round (one block per CU), and from 4 tokens on a long K split over blocks
+        // when that keeps the grid within a round (each block then reads only its slice of x).
         static const int cand[] = {8, 7, 4, 2, 1};
         StreamCfg best{1, 1, 1};
         double best_cost = -1.0;
         for (int nf : cand) {
             if (nf > 2 && !light) continue;
             if (nf > 4 && !packed) continue;
-            const int ks = split_for(nf, 1, forced ? forced : a.T >= 4 ? smax : 1);
-            const double blocks = (double)tiles_in(a.parts, nf * 16) * ks;
-            const double cost = (blocks > 256.0 ? blocks / 256.0 : 1.0) * (6.3 + 0.5 * nf);
-            if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = StreamCfg{nf, 1, ks}; }
+            for (int want = 1; want <= smax; want *= 2) {
+                if (forced ? want != 1 : (want > 1 && a.T < 4)) continue;
+                const int ks = split_for(nf, 1, forced ? forced : want);
+                const double cost = stream_tall_model_us(a, nf, ks);
+                if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = StreamCfg{nf, 1, ks}; }
+            }
         }
         return best;
     }
