@@ -189,3 +189,29 @@ def test_apply_on_cpu_layer_fails_loudly():
     assert lin.pq_packed_codes is None
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         lin(torch.zeros(2, 64, dtype=torch.bfloat16))
+
+
+def test_custom_ops_trace_with_fake_tensors():
+    """The ops are torch custom ops with fake implementations (the counterpart of the reference's schema +
+    register_fake pairs, vllm/_custom_ops.py:347-371): shapes and dtypes propagate under FakeTensorMode with no
+    GPU and no library call, which is what torch.compile and graph capture rely on."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from vllm_pq_amd import ops
+    if not ops._HAVE_CUSTOM_OP:
+        pytest.skip("this torch has no torch.library.custom_op")
+    with FakeTensorMode():
+        x = torch.empty(3, 5, 64, dtype=torch.bfloat16, device="cuda")
+        codes = torch.empty(96, 8, 1, dtype=torch.int8, device="cuda")
+        cb = torch.empty(2, 256, 1, 8, dtype=torch.bfloat16, device="cuda")
+        sc = torch.empty(96, 1, 1, 1, dtype=torch.bfloat16, device="cuda")
+        y = torch.ops.pq_amd.gemm(x, codes, cb, sc, [64, 32], None)
+        assert y.shape == (3, 5, 96) and y.dtype == torch.bfloat16 and y.device.type == "cuda"
+        packed = torch.empty(96 // 16 * 1024, dtype=torch.uint8, device="cuda")
+        y = torch.ops.pq_amd.gemm_packed(x, packed, codes, cb, sc, [64, 32], None)
+        assert y.shape == (3, 5, 96)
+        w = torch.ops.pq_amd.dequant(codes, cb, [64, 32], None)
+        assert w.shape == (96, 64) and w.dtype == torch.bfloat16
+        out = torch.empty(3, 5, 32, dtype=torch.bfloat16, device="cuda")
+        assert torch.ops.pq_amd.silu_and_mul(out, x) is None
+        assert torch.ops.pq_amd.fused_add_rms_norm(x, torch.empty_like(x), torch.empty(64, dtype=torch.bfloat16,
+                                                                                       device="cuda"), 1e-6) is None
