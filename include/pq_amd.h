@@ -64,6 +64,7 @@ typedef enum pq_status {
 #define PQ_CAP_BF16 (1ull << 4)
 #define PQ_CAP_FP16 (1ull << 5)
 #define PQ_CAP_ELEMENTWISE (1ull << 6) /* pq_silu_and_mul, pq_rms_norm, pq_fused_add_rms_norm */
+#define PQ_CAP_FUSED_SILU_MUL (1ull << 7) /* pq_gemm_packed_silu_mul runs fused for small batches */
 
 /* Version of this ABI (PQ_ABI_VERSION) and capability bits.  No reference counterpart. */
 int pq_version(void);
@@ -165,6 +166,24 @@ int pq_rms_norm(const void *x, int64_t x_row_stride, const void *weight, float e
                 int32_t dtype, void *out, int64_t out_row_stride, void *stream);
 int pq_fused_add_rms_norm(void *x, int64_t x_row_stride, void *residual, int64_t res_row_stride, const void *weight,
                           float eps, int32_t T, int32_t H, int32_t dtype, void *stream);
+
+/*
+ * gate_up_proj with its activation: y[t][n] = silu(g[t][n]) * u[t][n], n < I, where [g | u] = pq_gemm_packed of a
+ * layer with the two equal output partitions {I, I} (gate_proj, up_proj; M = 1) -- what LlamaMLP.forward computes
+ * with gate_up_proj followed by act_fn (vllm/model_executor/models/llama.py:89-93).  The result is bit-identical
+ * to pq_gemm_packed followed by pq_silu_and_mul.  For small batches of the d = 8 / one-byte-code format the
+ * activation runs in the epilogue of the streaming kernel (one launch, [T][2 I] never written);
+ * pq_gemm_silu_mul_is_fused() says whether it does for a problem.  Otherwise the library runs the two steps
+ * through `tmp`, caller-owned [T][2 I] in the act dtype (it may be NULL when the call is fused).
+ * `workspace` as for pq_gemm_packed.  No reference counterpart (the reference always runs two ops).
+ */
+int pq_gemm_silu_mul_is_fused(int32_t T, int32_t I, int32_t G, int32_t K, int32_t d, int32_t code_bytes,
+                              int32_t dtype);
+int pq_gemm_packed_silu_mul(const void *x, int32_t T, int64_t x_row_stride, const void *packed_codes,
+                            const void *codebooks, const void *scales, const void *bias /* nullable */, int32_t I,
+                            int32_t G, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype, void *y,
+                            int64_t y_row_stride, void *tmp /* nullable */, void *workspace, size_t workspace_bytes,
+                            void *stream);
 
 #ifdef __cplusplus
 }

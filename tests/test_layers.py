@@ -158,3 +158,40 @@ def test_gpu_layers_full_size_and_strided(dtype):
     with pytest.raises(ValueError):
         ops.rms_norm(torch.empty(2, 16, dtype=tdt, device=DEV), torch.empty(2, 16, dtype=tdt, device=DEV),
                      torch.empty(8, dtype=tdt, device=DEV), 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("T,I,Kin,bias", [(1, 512, 1024, False), (16, 14336, 4096, False), (7, 176, 1280, True),
+                                          (32, 1024, 512, True), (20, 48, 256, False), (100, 512, 1024, True)])
+def test_gpu_fused_gate_up_silu_mul(dtype, T, I, Kin, bias):
+    """The fused launch equals the GEMM followed by silu_and_mul bit for bit (same sums, same roundings), for
+    batches it fuses and for those it runs as two steps; ragged tiles, bias, both dtypes."""
+    from pq_testlib import Problem
+    from vllm_pq_amd import ops, _lib
+    p = Problem(900 + T, 256, 8, 1, [I, I], Kin, T, dtype, bias=bias).to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, [I, I])
+    y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, [I, I], p.bias_dev)
+    want = torch.empty(T, I, dtype=y.dtype, device=DEV)
+    ops.silu_and_mul(want, y)
+    got = ops.pq_gemm_packed_silu_mul(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, p.bias_dev)
+    fused = _lib.load().pq_gemm_silu_mul_is_fused(T, I, Kin // 8, 256, 8, 1, 1 if dtype == "bf16" else 0)
+    assert fused == (1 if T <= 16 else 0)
+    assert got.shape == (T, I)
+    if fused and ops.gemm_kernel_name(T, 2 * I, Kin // 8, 1, 256, 8, 1, y.dtype, [I, I], packed=True) != "mfma_stream_packed":
+        # the unfused GEMM ran on another kernel (other summation order): compare within the layers' tolerance
+        _close(bits_of(got), bits_of(want), 2, 0.9, f"fused vs tiled {dtype}")
+    else:
+        assert torch.equal(got, want)
+    # and through the linear method
+    from vllm_pq_amd import PQConfig
+    from vllm_pq_amd.host.linear import MergedColumnParallelLinear
+    layer = MergedColumnParallelLinear(Kin, [I, I], bias=bias, params_dtype=y.dtype, quant_config=PQConfig(8, 8, 1, 1))
+    layer.codes.data, layer.codebooks.data, layer.scales.data = p.codes, p.codebooks, p.scales
+    if bias:
+        layer.bias.data = p.bias
+    layer.to(DEV)
+    layer.quant_method.process_weights_after_loading(layer)
+    out = layer.quant_method.apply_silu_and_mul(layer, p.x_dev, layer.bias if bias else None)
+    assert out.shape == (T, I)
+    _close(bits_of(out), bits_of(want), 2, 0.9, f"method {dtype}")

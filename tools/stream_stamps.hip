@@ -8,7 +8,7 @@
 using namespace pq;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int NF, int TF>
+template <int NF, int TF, bool ACT = false>
 void run(const char *label, int T, int N, int G, int nparts) {
     const int K = 256, D = 8, M = 1;
     Parts parts; parts.num = nparts;
@@ -27,13 +27,17 @@ void run(const char *label, int T, int N, int G, int nparts) {
     constexpr int RF = NF * TF < 8 ? NF * TF : 8;
     size_t lds = (size_t)M * K * 2 * D * R;
     if ((size_t)ST_WAVES * RF * 1024 > lds) lds = (size_t)ST_WAVES * RF * 1024;
-    dim3 grid(tiles_in(parts, NF * 16), (T + 16 * TF - 1) / (16 * TF));
+    Parts gate = parts;
+    if (ACT) { gate.num = 1; gate.size[1] = 0; lds = 2 * 65536; }
+    dim3 grid(ACT ? tiles_in(gate, NF * 8) : tiles_in(parts, NF * 16), (T + 16 * TF - 1) / (16 * TF));
+    auto kern = gemm_stream_kernel<bf16_t, int8_t, D, M, NF, TF, true, 64, ACT>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536));
     const int nblk = grid.x * grid.y;
     CK(hipMalloc(&st, (size_t)nblk * 64)); CK(hipMemset(st, 0, (size_t)nblk * 64));
     for (int i = 0; i < copies; ++i) {
-        hipLaunchKernelGGL((gemm_stream_kernel<bf16_t, int8_t, D, M, NF, TF, true, 64>), grid, dim3(ST_THREADS), lds, 0,
+        hipLaunchKernelGGL(kern, grid, dim3(ST_THREADS), lds, 0,
                            (const uint16_t *)x, T, (int64_t)G * D, (const void *)pk[i], (const uint16_t *)cb,
-                           (const uint16_t *)sc, (const uint16_t *)st, make_tile_map(parts, NF * 16), G, K, 8, R, (uint16_t *)y, (int64_t)N, 1, nullptr, nullptr);
+                           (const uint16_t *)sc, (const uint16_t *)st, ACT ? make_tile_map(gate, NF * 8) : make_tile_map(parts, NF * 16), G, K, 8, R, (uint16_t *)y, (int64_t)N, 1, nullptr, nullptr, ACT ? N / 2 : 0);
         CK(hipDeviceSynchronize());
     }
     std::vector<unsigned long long> h((size_t)nblk * 8);
@@ -53,10 +57,9 @@ void run(const char *label, int T, int N, int G, int nparts) {
     CK(hipFree(x)); CK(hipFree(cb)); CK(hipFree(sc)); CK(hipFree(y)); CK(hipFree(st));
 }
 int main() {
-    run<1, 1>("o_proj", 16, 4096, 512, 1);
-    run<4, 2>("o_proj", 32, 4096, 512, 1);
-    run<4, 2>("gate_up", 32, 28672, 512, 2);
     run<8, 1>("gate_up", 16, 28672, 512, 2);
-    run<4, 4>("o_proj", 128, 4096, 512, 1);
+    run<8, 1, true>("gate_up fused act", 16, 28672, 512, 2);
+    run<8, 1>("gate_up", 1, 28672, 512, 2);
+    run<8, 1, true>("gate_up fused act", 1, 28672, 512, 2);
     return 0;
 }

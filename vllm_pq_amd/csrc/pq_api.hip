@@ -98,7 +98,7 @@ int pq_version(void) { return PQ_ABI_VERSION; }
 
 uint64_t pq_caps(void) {
     return PQ_CAP_DEQUANT | PQ_CAP_GEMM | PQ_CAP_MFMA_SMALL_T | PQ_CAP_MFMA_TILED | PQ_CAP_BF16 | PQ_CAP_FP16 |
-           PQ_CAP_ELEMENTWISE;
+           PQ_CAP_ELEMENTWISE | PQ_CAP_FUSED_SILU_MUL;
 }
 
 const char *pq_last_error(void) { return g_err; }
@@ -284,6 +284,61 @@ int pq_fused_add_rms_norm(void *x, int64_t x_row_stride, void *residual, int64_t
     if (T > 0 && H > 0 && !residual) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_fused_add_rms_norm: residual is NULL");
     return rms_common("pq_fused_add_rms_norm", x, x_row_stride, residual, res_row_stride, weight, eps, T, H, dtype, x,
                       x_row_stride, stream);
+}
+
+// ---- gate/up GEMM with the SiLU-and-mul fused in ---------------------------------------------------
+static int fill_gate_up(pq::GemmArgs &a, const char *fn, const void *x, int32_t T, int64_t x_row_stride,
+                        const void *packed_codes, const void *codebooks, const void *scales, const void *bias,
+                        int32_t I, int32_t G, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype, void *y,
+                        int64_t y_row_stride) {
+    if (I < 0 || I > INT32_MAX / 2) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: I=%d", fn, I);
+    const int32_t parts[2] = {I, I};
+    int rc = fill_gemm(a, fn, x, T, x_row_stride, packed_codes, codebooks, scales, bias, parts, 2, 2 * I, G, 1, K, d,
+                       code_bytes, dtype, y, 2 * (int64_t)I);
+    if (rc) return rc;
+    if (y_row_stride < I) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: y_row_stride=%lld < I=%d", fn, (long long)y_row_stride, I);
+    a.y_stride = y_row_stride;
+    a.packed = true;
+    return PQ_OK;
+}
+
+int pq_gemm_silu_mul_is_fused(int32_t T, int32_t I, int32_t G, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype) {
+    pq::GemmArgs a;
+    void *al = reinterpret_cast<void *>(uintptr_t(256));
+    if (fill_gate_up(a, "pq_gemm_silu_mul_is_fused", al, T, (int64_t)G * d, al, al, al, nullptr, I, G, K, d, code_bytes,
+                     dtype, al, I))
+        return 0;
+    return pq::packable(a.parts, d, K, 1, code_bytes) && pq::gemm_stream_act_supported(a) ? 1 : 0;
+}
+
+int pq_gemm_packed_silu_mul(const void *x, int32_t T, int64_t x_row_stride, const void *packed_codes,
+                            const void *codebooks, const void *scales, const void *bias, int32_t I, int32_t G,
+                            int32_t K, int32_t d, int32_t code_bytes, int32_t dtype, void *y, int64_t y_row_stride,
+                            void *tmp, void *workspace, size_t workspace_bytes, void *stream) {
+    const char *fn = "pq_gemm_packed_silu_mul";
+    pq::GemmArgs a;
+    int rc = fill_gate_up(a, fn, x, T, x_row_stride, packed_codes, codebooks, scales, bias, I, G, K, d, code_bytes,
+                          dtype, y, y_row_stride);
+    if (rc) return rc;
+    if (T == 0 || I == 0) return PQ_OK;
+    if (!y || !scales || !x || !packed_codes || !codebooks) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: NULL tensor pointer", fn);
+    if (!pq::packable(a.parts, d, K, 1, code_bytes))
+        return fail(PQ_ERR_UNSUPPORTED, "%s: this format has no packed layout (pq_packed_codes_bytes() == 0)", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (pq::gemm_stream_act_supported(a)) {
+        hipError_t e = pq::launch_gemm_stream_act(a, s);
+        if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "%s: %s", fn, hipGetErrorString(e));
+        return PQ_OK;
+    }
+    // not fused for this format / batch: the GEMM into tmp [T][2 I], then the stand-alone activation
+    if (!tmp)
+        return fail(PQ_ERR_WORKSPACE, "%s: T=%d is not fused for this format (pq_gemm_silu_mul_is_fused() == 0): "
+                    "tmp [T][2*I] is required", fn, T);
+    const int32_t parts[2] = {I, I};
+    rc = run_gemm(fn, true, x, T, x_row_stride, packed_codes, codebooks, scales, bias, parts, 2, 2 * I, G, 1, K, d,
+                  code_bytes, dtype, tmp, 2 * (int64_t)I, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    return pq_silu_and_mul(tmp, 2 * (int64_t)I, T, I, dtype, y, y_row_stride, stream);
 }
 
 }  // extern "C"

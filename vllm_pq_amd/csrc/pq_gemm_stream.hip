@@ -192,6 +192,36 @@ StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {
     return best;
 }
 
+// ---- fused gate/up + SiLU-and-mul ---------------------------------------------------------------------
+constexpr int STREAM_ACT_MAX_T = 16;   // beyond: 7x2 / tiled GEMM + stand-alone silu_and_mul is faster (measured)
+
+bool gemm_stream_act_supported(const GemmArgs &a) {
+    if (!a.packed || !stream_light_format(a) || !gemm_stream_supported(a)) return false;
+    if (a.parts.num != 2 || a.parts.size[0] != a.parts.size[1] || a.parts.size[0] % 16) return false;
+    if ((size_t)a.K * 16 * stream_replication<8>(a.K, 1) > (size_t)ST_MAX_LDS_CB) return false;
+    return a.T <= STREAM_ACT_MAX_T;
+}
+
+// NF (gate + up fragments per block) with the shortest modelled launch: rounds x (6.3 us + 0.5 us per fragment)
+int choose_stream_act_nf(const GemmArgs &a) {
+    static const int cand[] = {8, 4, 2};
+    int best = 8;
+    double best_cost = -1.0;
+    for (int nf : cand) {
+        const long blocks = (long)((a.parts.size[0] / 16 + nf / 2 - 1) / (nf / 2)) * ((a.T + 15) / 16);
+        const double cost = (double)((blocks + 255) / 256) * (6.3 + 0.5 * nf);
+        if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = nf; }
+    }
+    return best;
+}
+
+hipError_t launch_gemm_stream_act_bf16(const GemmArgs &a, hipStream_t stream);
+hipError_t launch_gemm_stream_act_fp16(const GemmArgs &a, hipStream_t stream);
+hipError_t launch_gemm_stream_act(const GemmArgs &a, hipStream_t stream) {
+    if (a.N == 0 || a.T == 0) return hipSuccess;
+    return a.dtype == PQ_DTYPE_BF16 ? launch_gemm_stream_act_bf16(a, stream) : launch_gemm_stream_act_fp16(a, stream);
+}
+
 hipError_t launch_gemm_stream_bf16(const GemmArgs &a, hipStream_t stream);
 hipError_t launch_gemm_stream_fp16(const GemmArgs &a, hipStream_t stream);
 

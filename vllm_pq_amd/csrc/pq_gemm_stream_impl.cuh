@@ -34,6 +34,7 @@
 #include "pq_kernels.h"
 #include "pq_gather.cuh"
 #include "pq_stream_geom.cuh"
+#include <atomic>
 
 namespace pq {
 
@@ -44,12 +45,16 @@ constexpr int stream_reduce_frags(int fr) { return fr <= 8 ? fr : fr % 8 == 0 ? 
 
 // ABL (diagnostic builds only; 0 in the library): bit 0 skips the LDS gather, bit 1 the MFMAs, bit 2 the
 // code loads, bit 3 the activation loads, bit 4 the codebook image, bit 5 the cross-wave sum + stores.
-template <typename AT, typename CodeT, int D, int M, int NF, int TF, bool PACKED, int ABL = 0>
+// ACT (fused SiLU-and-mul over a gate/up pair of equal partitions, act_rows rows each): the block's first NF/2
+// fragments are rows of the gate partition, the other NF/2 the same rows of the up partition, both codebooks
+// sit in the LDS image, and the epilogue stores y[t][n] = silu(gate[t][n]) * up[t][n], n < act_rows -- each
+// factor rounded to the act dtype first, exactly as the unfused GEMM followed by silu_and_mul rounds them.
+template <typename AT, typename CodeT, int D, int M, int NF, int TF, bool PACKED, int ABL = 0, bool ACT = false>
 __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
     const uint16_t *__restrict__ x, int T, int64_t x_stride, const void *__restrict__ codes_v,
     const uint16_t *__restrict__ codebooks, const uint16_t *__restrict__ scales, const uint16_t *__restrict__ bias,
     TileMap tmap, int G, int K, int nbits, int R, uint16_t *__restrict__ y, int64_t y_stride, int ksplit,
-    float *__restrict__ ws_part, unsigned *__restrict__ ws_cnt) {
+    float *__restrict__ ws_part, unsigned *__restrict__ ws_cnt, int act_rows = 0) {
     typedef typename Act<AT>::vec8 vec8;
     typedef StreamFmt<sizeof(CodeT), D, M> F;
     constexpr int CB = sizeof(CodeT);
@@ -61,6 +66,8 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
     constexpr int RF = stream_reduce_frags(FR);            // fragments per reduction round (<= 64 KiB of LDS)
     constexpr int ROUNDS = FR / RF;
     static_assert(KS % SUBK == 0 && FR % RF == 0, "unsupported tile shape");
+    constexpr int NFH = ACT ? NF / 2 : NF;                 // fragments of distinct output rows per block
+    static_assert(!ACT || (TF == 1 && NF % 2 == 0 && NF <= 8 && M == 1 && PACKED), "fused activation: one round, M = 1");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
     const int n_tiles_x = (int)gridDim.x / ksplit;
     const int zsplit = (int)blockIdx.x / n_tiles_x;
     const int tile_x = (int)blockIdx.x - zsplit * n_tiles_x;
-    const TileLoc loc = locate_tile(tmap, tile_x, NF * 16);
+    const TileLoc loc = locate_tile(tmap, tile_x, NFH * 16);   // ACT: the map covers the gate partition only
     const int t0 = blockIdx.y * (16 * TF);
     const int row_end = loc.row0 + loc.nrows;
     const int Kin = G * D;
@@ -119,7 +126,8 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
             const int nfr = (loc.nrows + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
-                const int f = f0 + (i < nfr ? i : nfr - 1);   // clamp: rows past the tile are never stored
+                const int ih = ACT ? i % NFH : i;             // ACT: fragments NFH.. are the up rows, act_rows further on
+                const int f = f0 + (ih < nfr ? ih : nfr - 1) + (ACT && i >= NFH ? act_rows >> 4 : 0);   // clamp: rows past the tile are never stored
                 if constexpr (ABL & 4) cd.cw[i] = u32x4{(uint32_t)(f * 977 + lane), (uint32_t)c, (uint32_t)lane * 31, 7u};
                 else cd.cw[i] = __builtin_nontemporal_load(&pk[((size_t)f * nchunks + c) * 64 + lane]);
             }
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
                         u32x4 fake{idx[0], 0u, 0u, 0u};
                         am = __builtin_bit_cast(vec8, fake);
                     } else {
-                        am = gather_frag<AT, D>(smem + m * cb_stride, idx, shift, lane_off);
+                        am = gather_frag<AT, D>(smem + (ACT ? (i >= NFH ? cb_stride : 0u) : m * cb_stride), idx, shift, lane_off);
                     }
                     // additive codebooks: the weight is the act-dtype-rounded sum of the entries, as the
                     // reference materialises it (embedding_bag output aqlm.py:60-64; __hadd2 in
@@ -201,8 +209,10 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
     // ---- everything the first chunk needs is requested before anything is waited for: the codebook
     // entries (needed first), the wave's first codes (HBM, the long latency), its first activations (L2)
     CodebookImage<D, ST_THREADS> img;
+    CodebookImage<D, ACT ? ST_THREADS : 1 << 20> img_up;   // ACT: the up partition's codebook, a second full image
     if constexpr (!(ABL & 16))
         img.load(reinterpret_cast<const unsigned char *>(codebooks) + (size_t)loc.part * M * K * EB, M * K, R, tid);
+    if constexpr (ACT) img_up.load(reinterpret_cast<const unsigned char *>(codebooks) + (size_t)K * EB, K, R, tid);
     Codes cA, cB;
     XSub X[2];
     if (c_begin + wave < c_end) {
@@ -225,8 +235,19 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
             bi_raw[r][e] = bias ? bias[n] : (uint16_t)0;
         }
     }
+    uint16_t sc_up[4] = {0, 0, 0, 0}, bi_up[4] = {0, 0, 0, 0};   // ACT: the same for the up rows of the thread's fragment
+    if constexpr (ACT) {
+        const int nb = loc.row0 + 16 * ((tid >> 6) % NFH) + q * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = (nb + e < row_end ? nb + e : row_end - 1) + act_rows;
+            sc_up[e] = scales[n];
+            bi_up[e] = bias ? bias[n] : (uint16_t)0;
+        }
+    }
     if constexpr (ABL & 64) if (tid == 0) stamps[1] = wall_clock64();   // loads issued
     if constexpr (!(ABL & 16)) img.store(smem, M * K, R, tid);
+    if constexpr (ACT) img_up.store(smem + cb_stride, K, R, tid);
     __syncthreads();
     if constexpr (ABL & 64) if (tid == 0) stamps[2] = wall_clock64();   // image built
 
@@ -298,7 +319,42 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
         }
         __syncthreads();
         if constexpr (ABL & 64) if (tid == 0 && r == 0) stamps[4] = wall_clock64();   // all waves done
-        if (tid < RF * 64) {
+        if constexpr (ACT) {
+            if (tid < NFH * 64) {
+                const int f = tid >> 6;
+                f32x4 g = red[f * 64 + lane], u = red[(f + NFH) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < ST_WAVES; ++w) {
+                    const f32x4 vg = red[(w * RF + f) * 64 + lane], vu = red[(w * RF + f + NFH) * 64 + lane];
+                    g.x += vg.x; g.y += vg.y; g.z += vg.z; g.w += vg.w;
+                    u.x += vu.x; u.y += vu.y; u.z += vu.z; u.w += vu.w;
+                }
+                const int t = t0 + r16;
+                const int nb = loc.row0 + 16 * f + q * 4;
+                if (t < T && nb < row_end) {
+                    uint16_t h[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // the two GEMM outputs as the unfused kernel rounds them, then silu_and_mul's two roundings
+                        const float yg = Act<AT>::to_f32(Act<AT>::from_f32(g[e] * Act<AT>::to_f32(sc_raw[0][e]) + Act<AT>::to_f32(bi_raw[0][e])));
+                        const float yu = Act<AT>::to_f32(Act<AT>::from_f32(u[e] * Act<AT>::to_f32(sc_up[e]) + Act<AT>::to_f32(bi_up[e])));
+                        const float sg = Act<AT>::to_f32(Act<AT>::from_f32(yg / (1.0f + expf(-yg))));
+                        h[e] = Act<AT>::from_f32(sg * yu);
+                    }
+                    uint16_t *yp = y + (size_t)t * y_stride + nb;
+                    if (nb + 4 <= row_end && (reinterpret_cast<uintptr_t>(yp) & 7) == 0) {
+                        u32x2 o2;
+                        o2.x = h[0] | ((uint32_t)h[1] << 16);
+                        o2.y = h[2] | ((uint32_t)h[3] << 16);
+                        *reinterpret_cast<u32x2 *>(yp) = o2;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (nb + e < row_end) yp[e] = h[e];
+                    }
+                }
+            }
+        } else if (tid < RF * 64) {
             const int f = tid >> 6;
             f32x4 sum = red[f * 64 + lane];
 #pragma unroll
@@ -389,6 +445,47 @@ static hipError_t launch_nf(const GemmArgs &a, int ksplit, hipStream_t stream) {
                        static_cast<const uint16_t *>(a.bias), make_tile_map(a.parts, NF * 16), a.G, a.K, nbits, R,
                        static_cast<uint16_t *>(a.y), a.y_stride, ksplit, ws_part, ws_cnt);
     return hipGetLastError();
+}
+
+// Fused gate/up GEMM + SiLU-and-mul (d = 8, one codebook, one-byte codes, packed): a.parts holds the two equal
+// partitions, a.y is [T][N / 2].
+template <typename AT, int NF>
+static hipError_t launch_act_nf(const GemmArgs &a, hipStream_t stream) {
+    const int rows = a.parts.size[0];
+    const int R = stream_replication<8>(a.K, 1);            // a full image per codebook: 2 x 64 KiB at K = 256
+    const int nbits = __builtin_ctz((unsigned)a.K);
+    size_t lds = (size_t)2 * a.K * 16 * R;
+    const size_t red = (size_t)ST_WAVES * NF * 64 * 16;
+    if (red > lds) lds = red;
+    Parts gate;
+    gate.num = 1;
+    for (int p = 0; p < PQ_MAX_PARTS; ++p) gate.size[p] = p == 0 ? rows : 0;
+    const dim3 grid(tiles_in(gate, NF * 8), (a.T + 15) / 16);
+    auto kern = gemm_stream_kernel<AT, int8_t, 8, 1, NF, 1, true, 0, true>;
+    static std::atomic<bool> attr_set[64];   // per device: the kernel may use more than the default 64 KiB of LDS
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * ST_MAX_LDS_CB);
+        if (e != hipSuccess) return e;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(ST_THREADS), lds, stream,
+                       static_cast<const uint16_t *>(a.x), a.T, a.x_stride, a.codes,
+                       static_cast<const uint16_t *>(a.codebooks), static_cast<const uint16_t *>(a.scales),
+                       static_cast<const uint16_t *>(a.bias), make_tile_map(gate, NF * 8), a.G, a.K, nbits, R,
+                       static_cast<uint16_t *>(a.y), a.y_stride, 1, nullptr, nullptr, rows);
+    return hipGetLastError();
+}
+
+template <typename AT>
+static hipError_t launch_act_at(const GemmArgs &a, hipStream_t stream) {
+    switch (choose_stream_act_nf(a)) {
+    case 8: return launch_act_nf<AT, 8>(a, stream);
+    case 4: return launch_act_nf<AT, 4>(a, stream);
+    default: return launch_act_nf<AT, 2>(a, stream);
+    }
 }
 
 template <typename AT, typename CodeT, int D, int M>

@@ -55,6 +55,12 @@ bool stream_ksplit_ok(const GemmArgs &a, int nf, int tf, int ksplit);
 size_t stream_workspace_bytes(int T, int N, int G, int M, int K, int d, int code_bytes);
 StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us);
 hipError_t launch_gemm_stream(const GemmArgs &a, hipStream_t stream);
+// Fused gate/up GEMM + SiLU-and-mul on the streaming kernel: a.parts = two equal partitions (gate, up), a.y is
+// [T][N / 2].  supported(): d = 8, one codebook, one-byte codes, packed, partitions a multiple of 16 rows, and a
+// batch small enough that the fused launch beats the tiled GEMM followed by the stand-alone activation.
+bool gemm_stream_act_supported(const GemmArgs &a);
+int choose_stream_act_nf(const GemmArgs &a);
+hipError_t launch_gemm_stream_act(const GemmArgs &a, hipStream_t stream);
 
 // Load-time re-layout of the codes for the MFMA kernels.
 bool stream_format_supported(int d, int K, int M, int code_bytes);

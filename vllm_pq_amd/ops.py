@@ -244,6 +244,68 @@ def pq_dequant(codes: torch.Tensor, codebooks: torch.Tensor, codebook_partition_
     return _pq_dequant_impl(codes, codebooks, codebook_partition_sizes, scales)
 
 
+# ---- gate_up_proj with its activation ------------------------------------------------------------
+def _pq_gemm_packed_silu_mul_impl(input: torch.Tensor, packed_codes: torch.Tensor, codes: torch.Tensor,
+                                  codebooks: torch.Tensor, scales: torch.Tensor,
+                                  bias: Optional[torch.Tensor]) -> torch.Tensor:
+    L = _lib.load()
+    dev = _check_device(input, packed_codes, codes, codebooks, scales, bias)
+    N, G, M, K, d, parts = _format(codes, codebooks, [codes.shape[0] // 2, codes.shape[0] - codes.shape[0] // 2])
+    I = N // 2
+    if N != 2 * I or M != 1:
+        raise ValueError("pq_gemm_packed_silu_mul: two equal output partitions (gate, up) and one codebook expected")
+    if input.dtype != codebooks.dtype or input.shape[-1] != G * d:
+        raise ValueError(f"input {tuple(input.shape)} {input.dtype} does not match the weight ({G * d} features, "
+                         f"{codebooks.dtype})")
+    if scales.numel() != N or scales.dtype != input.dtype:
+        raise ValueError("scales must hold one value of the activation dtype per output row")
+    if bias is not None and (bias.numel() != N or bias.dtype != input.dtype):
+        raise ValueError("bias must hold one value of the activation dtype per output row")
+    x2 = input.reshape(-1, input.shape[-1])
+    if x2.stride(-1) != 1 or x2.data_ptr() % 16 or x2.stride(0) % 8:
+        x2 = x2.contiguous()
+    T = x2.shape[0]
+    out = torch.empty((T, I), dtype=input.dtype, device=dev)
+    if T and I:
+        cb = _CODE_BYTES[codes.dtype]
+        fused = L.pq_gemm_silu_mul_is_fused(T, I, G, K, d, cb, _DTYPE[input.dtype])
+        tmp = None if fused else torch.empty((T, N), dtype=input.dtype, device=dev)
+        ws = _WORKSPACE.get(dev.index)
+        with torch.cuda.device(dev):
+            rc = L.pq_gemm_packed_silu_mul(
+                x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, packed_codes.data_ptr(),
+                codebooks.contiguous().data_ptr(), scales.contiguous().data_ptr(),
+                bias.contiguous().data_ptr() if bias is not None else None, I, G, K, d, cb, _DTYPE[input.dtype],
+                out.data_ptr(), I, tmp.data_ptr() if tmp is not None else None,
+                ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream_ptr(dev))
+        if rc:
+            _raise(rc)
+    return out.reshape(input.shape[:-1] + (I,))
+
+
+if _HAVE_CUSTOM_OP:
+
+    @torch.library.custom_op("pq_amd::gemm_packed_silu_mul", mutates_args=(), device_types="cuda")
+    def _gemm_packed_silu_mul_op(input: torch.Tensor, packed_codes: torch.Tensor, codes: torch.Tensor,
+                                 codebooks: torch.Tensor, scales: torch.Tensor,
+                                 bias: Optional[torch.Tensor]) -> torch.Tensor:
+        return _pq_gemm_packed_silu_mul_impl(input, packed_codes, codes, codebooks, scales, bias)
+
+    @_gemm_packed_silu_mul_op.register_fake
+    def _gemm_packed_silu_mul_fake(input, packed_codes, codes, codebooks, scales, bias):
+        return input.new_empty(input.shape[:-1] + (codes.shape[0] // 2,))
+
+
+def pq_gemm_packed_silu_mul(input: torch.Tensor, packed_codes: torch.Tensor, codes: torch.Tensor,
+                            codebooks: torch.Tensor, scales: torch.Tensor,
+                            bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """silu(g) * u with [g | u] = pq_gemm_packed(input, ...) of a gate/up layer (two equal output partitions):
+    bit-identical to pq_gemm_packed followed by silu_and_mul, in one launch for small batches."""
+    if _HAVE_CUSTOM_OP and input.is_cuda:
+        return torch.ops.pq_amd.gemm_packed_silu_mul(input, packed_codes, codes, codebooks, scales, bias)
+    return _pq_gemm_packed_silu_mul_impl(input, packed_codes, codes, codebooks, scales, bias)
+
+
 # ---- the element-wise neighbours of the linears -------------------------------------------------
 # Same names, argument order and in-place conventions as the reference's wrappers
 # (vllm/_custom_ops.py:151-158 rms_norm / fused_add_rms_norm; torch.ops._C.silu_and_mul as called from

@@ -173,6 +173,20 @@ class PQLinearMethod(LinearMethodBase):
             return ops.pq_gemm_packed(x, packed, layer.codes, codebooks, layer.scales, parts, bias)
         return ops.pq_gemm(x, layer.codes, codebooks, layer.scales, parts, bias)
 
+    def apply_silu_and_mul(self, layer: torch.nn.Module, x: torch.Tensor,
+                           bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`SiluAndMul()(self.apply(layer, x, bias))` for a gate/up layer (two equal output partitions), the pair
+        LlamaMLP.forward runs back to back (vllm/model_executor/models/llama.py:89-93): the same values, with the
+        activation in the GEMM's epilogue when the library fuses it (decode batches)."""
+        parts = list(getattr(layer.codebooks, "output_partition_sizes", []))
+        packed = getattr(layer, "pq_packed_codes", None)
+        if packed is None or len(parts) != 2 or parts[0] != parts[1] or layer.codes.shape[2] != 1:
+            y = self.apply(layer, x, bias)
+            out = torch.empty(y.shape[:-1] + (y.shape[-1] // 2,), dtype=y.dtype, device=y.device)
+            ops.silu_and_mul(out, y)
+            return out
+        return ops.pq_gemm_packed_silu_mul(x, packed, layer.codes, layer.codebooks, layer.scales, bias)
+
 
 def register() -> None:
     """Idempotent registration of the "pq" method (entry point for vLLM's `vllm.general_plugins`
