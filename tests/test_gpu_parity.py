@@ -419,3 +419,25 @@ def test_tiled_kernel_long_k_every_shape_and_format(ops, monkeypatch, fmt, cfg):
     y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)
     _, y32 = p.oracle_gemm(order=2)
     assert_close_to_exact(bits_of(y), y32, "fp16" if cfg % 2 else "bf16", f"K={K} d={d} M={M} cfg {cfg}")
+
+
+# ---- the per-rank shapes of the tensor-parallel configurations ------------------------------------------
+TP_SHAPES = [  # what one rank holds (column-parallel: rows split; row-parallel: input features split)
+    ("8B/tp4.qkv", [1024, 256, 256], 4096), ("8B/tp4.o", [4096], 1024), ("8B/tp4.gate_up", [3584, 3584], 4096),
+    ("8B/tp4.down", [4096], 3584), ("70B/tp8.qkv", [1024, 128, 128], 8192), ("70B/tp8.o", [8192], 1024),
+    ("70B/tp8.gate_up", [3584, 3584], 8192), ("70B/tp8.down", [8192], 3584)]
+
+
+@pytest.mark.parametrize("name,parts,Kin", TP_SHAPES, ids=[s[0] for s in TP_SHAPES])
+@pytest.mark.parametrize("T", [2, 16, 48, 300])
+def test_tp_rank_shapes_against_oracle(ops, name, parts, Kin, T):
+    """Llama-3-8B TP=4 and Llama-3-70B TP=8 per-rank linears against the CPU oracle (a sample of the tokens for the
+    largest ones keeps the oracle within seconds), packed path, whatever kernel and tile shape the library picks."""
+    p = Problem(sum(parts) % 1000 + Kin % 97 + T, 256, 8, 1, parts, Kin, T, "bf16", bias=False).to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)
+    rows = np.arange(T) if T <= 48 else np.arange(0, T, 13)
+    a = p.np_args()
+    _, y32 = orc.gemm(a["x"][rows], a["codes"], a["codebooks"], a["scales"], parts, None, "bf16", order=2,
+                      acc_double=True, want_f32=True)
+    assert_close_to_exact(bits_of(y)[rows], y32, "bf16", f"{name} T={T}")
