@@ -53,3 +53,55 @@ def fused_vs_separate(T, copies=24):
 if len(sys.argv) > 2 and sys.argv[2] == "fused":
     for T in (1, 4, 16, 24, 32, 64):
         fused_vs_separate(T)
+
+
+def layer_chain(T, layers=32):
+    """All linears and element-wise steps of `layers` Llama-3-8B decoder layers back to back (attention itself
+    left out: the value heads stand in), one HIP-graph replay per step: fused MLP entry against the two-step one."""
+    import bench as B
+    from vllm_pq_amd.host.layers import RMSNorm
+    from vllm_pq_amd import ops
+    dev, dt = torch.device("cuda:0"), torch.bfloat16
+    stack = B.build_stack(1, dev, dt, layers=layers)
+    norms = [(RMSNorm(4096, 1e-5).to(dev), RMSNorm(4096, 1e-5).to(dev)) for _ in range(layers)]
+    for a, b in norms:
+        a.weight.data = a.weight.data.to(dt); b.weight.data = b.weight.data.to(dt)
+    x0 = torch.randn(T, 4096, device=dev).to(dt)
+
+    def step(fused):
+        h, res = x0.clone(), x0.clone()
+        for blk, (n1, n2) in zip(stack, norms):
+            h, res = n1(h, res)
+            qkv, _ = blk["qkv_proj"](h)
+            h, _ = blk["o_proj"](qkv[:, :4096])
+            h, res = n2(h, res)
+            gu = blk["gate_up_proj"]
+            if fused:
+                a = gu.quant_method.apply_silu_and_mul(gu, h)
+            else:
+                y, _ = gu(h)
+                a = torch.empty(T, 14336, device=dev, dtype=dt)
+                ops.silu_and_mul(a, y)
+            h, _ = blk["down_proj"](a)
+        return h
+
+    out = {}
+    for fused in (False, True):
+        step(fused)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step(fused)
+        g.replay(); torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        out[fused] = best
+    print(f"layer chain x{layers} T={T:4d}: two-step MLP {out[False]:7.3f} ms   fused MLP entry {out[True]:7.3f} ms")
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "chain":
+    for T in (1, 16, 64, 4096):
+        layer_chain(T)
