@@ -441,3 +441,36 @@ def test_tp_rank_shapes_against_oracle(ops, name, parts, Kin, T):
     _, y32 = orc.gemm(a["x"][rows], a["codes"], a["codebooks"], a["scales"], parts, None, "bf16", order=2,
                       acc_double=True, want_f32=True)
     assert_close_to_exact(bits_of(y)[rows], y32, "bf16", f"{name} T={T}")
+
+
+# ---- whatever the dispatcher picks --------------------------------------------------------------------
+def _random_problems():
+    rng = np.random.RandomState(2024)
+    fmts = [(256, 8, 1), (16, 2, 1), (4096, 4, 1), (256, 8, 2), (4096, 8, 1), (16, 8, 1), (256, 4, 1), (4096, 2, 1)]
+    out = []
+    for i in range(48):
+        K, d, M = fmts[i % len(fmts)]
+        nparts = int(rng.randint(1, 4))
+        parts = [int(rng.randint(1, 40)) * 16 for _ in range(nparts)]
+        Kin = int(rng.choice([256, 512, 1024, 1536, 2048, 4096]))
+        T = int(rng.choice([1, 2, 3, 7, 16, 17, 24, 33, 48, 64, 100, 129, 200]))
+        out.append((i, K, d, M, parts, Kin, T, "fp16" if i % 3 == 0 else "bf16", bool(i % 2)))
+    return out
+
+
+@pytest.mark.parametrize("i,K,d,M,parts,Kin,T,dtype,bias", _random_problems(),
+                         ids=lambda v: str(v) if not isinstance(v, list) else "x".join(map(str, v)))
+def test_random_problems_default_dispatch(ops, i, K, d, M, parts, Kin, T, dtype, bias):
+    """Seeded random formats, partitions, widths and batch sizes through the default kernel choice (tile shape,
+    K split, stream or tiled), packed and reference layout, with the K-split workspace in place."""
+    p = Problem(7000 + i, K, d, M, parts, Kin, T, dtype, bias=bias).to(DEV)
+    N, G = sum(parts), Kin // d
+    ops.ensure_workspace(torch.device(DEV), ops.workspace_bytes(128, N, G, M, K, d, p.codes.element_size(),
+                                                                p.x.dtype))
+    _, y32 = p.oracle_gemm(order=2)
+    y = ops.pq_gemm(p.x_dev, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    assert_close_to_exact(bits_of(y), y32, dtype, f"case {i} reference layout")
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    if packed is not None:
+        y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+        assert_close_to_exact(bits_of(y), y32, dtype, f"case {i} packed")
