@@ -82,3 +82,48 @@ def test_decoder_block_composes(T):
     from vllm_pq_amd.host.layers import SiluAndMul
     gu, _ = gate_up(h2)
     assert torch.equal(SiluAndMul()(gu), act) or T > 16
+
+
+def test_ops_capture_into_a_hip_graph():
+    """No op allocates through the library, synchronises or reads host state that changes between replays: a
+    captured chain (norm -> gate_up + SiLU-and-mul, fused and two-step -> down with a split K) replays with new
+    inputs to the values the eager calls give."""
+    from pq_testlib import Problem
+    from vllm_pq_amd import ops
+    T, H, inter = 8, 512, 1024
+    gu = Problem(1, 256, 8, 1, [inter, inter], H, T, "bf16").to(DEV)
+    dn = Problem(2, 256, 8, 1, [H], 16 * inter, T, "bf16").to(DEV)       # long K: the K-split path
+    pg = ops.pq_repack_codes(gu.codes_dev, gu.codebooks_dev, [inter, inter])
+    pd = ops.pq_repack_codes(dn.codes_dev, dn.codebooks_dev, [H])
+    ops.ensure_workspace(torch.device(DEV), ops.workspace_bytes(128, H, 16 * inter // 8, 1, 256, 8, 1, torch.bfloat16))
+    w = torch.ones(H, dtype=torch.bfloat16, device=DEV)
+    x = torch.randn(T, H, device=DEV).to(torch.bfloat16)
+    wide = torch.randn(T, 16 * inter, device=DEV).to(torch.bfloat16)
+
+    def chain():
+        a = torch.empty_like(x)
+        ops.rms_norm(a, x, w, 1e-5)
+        f = ops.pq_gemm_packed_silu_mul(a, pg, gu.codes_dev, gu.codebooks_dev, gu.scales_dev, None)
+        y = ops.pq_gemm_packed(a, pg, gu.codes_dev, gu.codebooks_dev, gu.scales_dev, [inter, inter], None)
+        s = torch.empty(T, inter, dtype=y.dtype, device=DEV)
+        ops.silu_and_mul(s, y)
+        d = ops.pq_gemm_packed(wide, pd, dn.codes_dev, dn.codebooks_dev, dn.scales_dev, [H], None)
+        return f, s, d
+
+    chain()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = chain()
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        x.copy_(torch.randn(T, H, device=DEV).to(torch.bfloat16))
+        wide.copy_(torch.randn(T, 16 * inter, device=DEV).to(torch.bfloat16))
+        g.replay()
+        torch.cuda.synchronize()
+        got = [o.clone() for o in outs]
+        want = chain()
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+        assert torch.equal(got[0], got[1])                      # fused == two-step
