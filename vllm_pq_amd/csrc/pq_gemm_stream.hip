@@ -68,7 +68,8 @@ static double stream_model_us(const GemmArgs &a, int nf, int tf, int ksplit) {
     return rounds * (fixed + (ksplit > 1 ? 2.0 : 0.0) + per_wave * ((ks / subk) * 1.9 + tall));   // + 2 us: partial sums, count, re-read
 }
 
-// The same for blocks of one token fragment (TF = 1) and NF weight fragments: 5.3 us fixed; a wave's first
+// The same for blocks of one token fragment (TF = 1) and NF weight fragments: 5.3 us fixed (3.8 when a short K
+// leaves three quarters of the waves without a chunk, in proportion between); a wave's first
 // chunk costs 1 us for its activations plus 0.5 us per weight fragment gathered (a chunk of 16 k-steps;
 // shorter chunks in proportion), every further chunk of the wave 1.55 us per activation sub-load (round trips
 // that nothing overlaps) + 0.2 us per fragment.  Measured at 4 <= T <= 128 on 4096 x 4096 ... 8192 x 8192 layers.
@@ -82,7 +83,8 @@ static double stream_tall_model_us(const GemmArgs &a, int nf, int ksplit) {
     const int nsub = ks > 8 ? ks / 8 : 1;   // sub-loads per chunk at TF = 1
     const double scale = ks / 16.0;
     const double chunks_us = scale * (1.0 + 0.5 * nf) + (per_wave - 1.0) * (1.55 * nsub + scale * 0.2 * nf);
-    return rounds * (5.3 + (ksplit > 1 ? 2.0 : 0.0) + chunks_us);
+    const double busy = nchunks / 8.0 < 1.0 ? nchunks / 8.0 : 1.0;   // waves of a block that have a chunk at all
+    return rounds * (3.3 + 2.0 * busy + (ksplit > 1 ? 2.0 : 0.0) + chunks_us);
 }
 
 // ---- K split over blocks ---------------------------------------------------------------------------
