@@ -55,20 +55,26 @@ def main():
     ap.add_argument("--out", default="gpurun_out/autotune.csv")
     ap.add_argument("--tokens", default="1,4,16,32,64,128,256,512")
     ap.add_argument("--full", action="store_true", help="all per-rank model shapes (default: Llama-3-8B TP=1)")
+    ap.add_argument("--square", action="store_true",
+                    help="the codebook sweep instead: Kin = N in {4096, 8192} x K in {16, 256, 4096} x d in {2, 4, 8}")
     args = ap.parse_args()
-    dev, dt, K, d = "cuda", torch.bfloat16, 256, 8
-    shapes = MODEL_SHAPES if args.full else MODEL_SHAPES[:4]
+    dev, dt = "cuda", torch.bfloat16
+    shapes = [(n, p, k, 256, 8) for (n, p, k) in (MODEL_SHAPES if args.full else MODEL_SHAPES[:4])]
+    if args.square:
+        shapes = [(f"sq{n}.K{K}.d{d}", [n], n, K, d) for n in (4096, 8192) for K in (16, 256, 4096) for d in (2, 4, 8)]
     rows = []
-    for name, parts, kin in shapes:
+    for name, parts, kin, K, d in shapes:
         N, G = sum(parts), kin // d
-        copies = max(2, min(48, int(400e6 / (N * G)) + 1))
+        cbytes = 1 if K <= 256 else 2
+        copies = max(2, min(48, int(400e6 / (N * G * cbytes)) + 1))
         sets = []
         for _ in range(copies):
-            codes = torch.randint(-128, 128, (N, G, 1), device=dev, dtype=torch.int32).to(torch.int8)
+            codes = torch.randint(-(K // 2), K // 2, (N, G, 1), device=dev, dtype=torch.int32).to(
+                torch.int8 if cbytes == 1 else torch.int16)
             cb = torch.randn(len(parts), K, 1, d, device=dev).to(dt)
             sc = (torch.rand(N, 1, 1, 1, device=dev) + 0.5).to(dt)
             sets.append((codes, cb, sc, ops.pq_repack_codes(codes, cb, parts)))
-        ops.ensure_workspace(torch.device(dev, 0), ops.workspace_bytes(128, N, G, 1, K, d, 1, dt))
+        ops.ensure_workspace(torch.device(dev, 0), ops.workspace_bytes(128, N, G, 1, K, d, cbytes, dt))
         for T in [int(t) for t in args.tokens.split(",")]:
             x = torch.randn(T, kin, device=dev).to(dt)
             use = sets if T <= 512 else sets[:4]
