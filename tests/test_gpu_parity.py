@@ -474,3 +474,29 @@ def test_random_problems_default_dispatch(ops, i, K, d, M, parts, Kin, T, dtype,
     if packed is not None:
         y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
         assert_close_to_exact(bits_of(y), y32, dtype, f"case {i} packed")
+
+
+@pytest.mark.parametrize("T,bias", [(4, False), (40, False), (40, True), (300, False)])
+def test_codebook_too_large_for_lds_takes_the_dequant_route(ops, T, bias):
+    """AQLM 1x16 (65536 entries of 8, two-byte codes): no MFMA kernel.  Small batches run the generic fused kernel,
+    larger ones dequantise + dense GEMM in the reference's order for that route (aqlm.py:143-156: the GEMM output
+    is scaled, or with a bias the weight is); both against the oracle in that order."""
+    from vllm_pq_amd import PQConfig
+    from vllm_pq_amd.host.linear import MergedColumnParallelLinear
+    parts, Kin = [96, 160], 256
+    p = Problem(4242 + T, 65536, 8, 1, parts, Kin, T, "fp16", bias=bias)
+    layer = MergedColumnParallelLinear(Kin, parts, bias=bias, params_dtype=torch.float16, quant_config=PQConfig(8, 16, 1, 1))
+    layer.codes.data, layer.codebooks.data, layer.scales.data = p.codes, p.codebooks, p.scales
+    if bias:
+        layer.bias.data = p.bias
+    layer.to(DEV)
+    layer.quant_method.process_weights_after_loading(layer)
+    assert layer.pq_packed_codes is None and layer.pq_dequant_route
+    y, _ = layer(p.x.to(DEV))
+    a = p.np_args()
+    if T <= 8:
+        _, y32 = p.oracle_gemm(order=2)
+        assert_close_to_exact(bits_of(y), y32, "fp16", "generic kernel")
+    else:
+        ref = orc.gemm(a["x"], a["codes"], a["codebooks"], a["scales"], parts, a["bias"], "fp16", order=1 if not bias else 0)
+        assert_close_to_reference_order(bits_of(y), ref, "fp16", "dequant route")

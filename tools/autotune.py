@@ -57,11 +57,15 @@ def main():
     ap.add_argument("--full", action="store_true", help="all per-rank model shapes (default: Llama-3-8B TP=1)")
     ap.add_argument("--square", action="store_true",
                     help="the codebook sweep instead: Kin = N in {4096, 8192} x K in {16, 256, 4096} x d in {2, 4, 8}")
+    ap.add_argument("--custom", default="", help="one more shape: 'rows,rows,..:in_features'")
     args = ap.parse_args()
     dev, dt = "cuda", torch.bfloat16
     shapes = [(n, p, k, 256, 8) for (n, p, k) in (MODEL_SHAPES if args.full else MODEL_SHAPES[:4])]
     if args.square:
         shapes = [(f"sq{n}.K{K}.d{d}", [n], n, K, d) for n in (4096, 8192) for K in (16, 256, 4096) for d in (2, 4, 8)]
+    if args.custom:
+        ps, kin = args.custom.split(":")
+        shapes = [("custom " + args.custom, [int(v) for v in ps.split(",")], int(kin), 256, 8)]
     rows = []
     for name, parts, kin, K, d in shapes:
         N, G = sum(parts), kin // d

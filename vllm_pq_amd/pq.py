@@ -13,11 +13,14 @@ vllm/model_executor/layers/quantization/aqlm.py:
     PQLinearMethod      <-> AQLMLinearMethod :220-374 (create_weights :230-323, apply :325-374)
 Differences, all on purpose: bf16 as well as fp16 activations; every (K, d, M) goes to the fused HIP
 kernels (the reference only accelerates d == 8 with (K, M) in {(256, 2), (65536, 1)} and falls back to
-PyTorch otherwise, aqlm.py:344-374); there is no PyTorch fallback here.
+PyTorch otherwise, aqlm.py:344-374); there is no CPU path here.  A format whose codebook does not fit LDS
+(65536 entries) has no MFMA kernel: up to 8 tokens it runs on the generic fused kernel, beyond that as the
+library's dequantisation kernel followed by a dense GEMM, the reference's own route for such batches.
 """
 from typing import Any, Dict, List, Optional
 
 import torch
+import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from . import ops
@@ -153,9 +156,19 @@ class PQLinearMethod(LinearMethodBase):
         # layout, which the checkpoint loaders and pq_dequant use).  On a CPU-resident layer (weights
         # not moved to the GPU yet) there is nothing to do: apply() needs the GPU anyway.
         layer.pq_packed_codes = None
+        layer.pq_dequant_route = False
         if layer.codes.is_cuda:
             parts = getattr(layer.codebooks, "output_partition_sizes", [])
             layer.pq_packed_codes = ops.pq_repack_codes(layer.codes.data, layer.codebooks.data, parts)
+            # Formats no MFMA kernel takes (a codebook that does not fit LDS, such as AQLM's 1x16 with 65536
+            # entries) run on the generic one-wave-per-row kernel: fine for a few tokens, far too slow for a
+            # prefill.  Larger batches take the route the reference's own fast path takes there
+            # (optimized_dequantize_gemm, aqlm.py:132-156): dequantise, then a dense GEMM.
+            N, G, M = layer.codes.shape
+            K, d = layer.codebooks.shape[1], layer.codebooks.shape[3]
+            layer.pq_dequant_route = ops.gemm_kernel_name(
+                64, N, G, M, K, d, layer.codes.element_size(), layer.codebooks.dtype, parts or [N],
+                packed=layer.pq_packed_codes is not None) == "generic"
             if layer.pq_packed_codes is not None:
                 # scratch for the K-split launches (long-K layers, up to 128 tokens): one buffer per device,
                 # sized here, at load time, for the largest batch those launches take
@@ -171,6 +184,16 @@ class PQLinearMethod(LinearMethodBase):
         packed = getattr(layer, "pq_packed_codes", None)
         if packed is not None:
             return ops.pq_gemm_packed(x, packed, layer.codes, codebooks, layer.scales, parts, bias)
+        if getattr(layer, "pq_dequant_route", False) and x.numel() // x.shape[-1] > GENERIC_KERNEL_MAX_TOKENS:
+            # the reference's order for this route (aqlm.py:143-156): without bias the GEMM output is scaled,
+            # with bias the weight is scaled first
+            w = ops.pq_dequant(layer.codes, codebooks, parts)
+            if bias is None:
+                out = F.linear(x, w)
+                out *= layer.scales.view(-1)
+                return out
+            w *= layer.scales.view(-1, 1)
+            return F.linear(x, w, bias)
         return ops.pq_gemm(x, layer.codes, codebooks, layer.scales, parts, bias)
 
     def apply_silu_and_mul(self, layer: torch.nn.Module, x: torch.Tensor,
@@ -186,6 +209,11 @@ class PQLinearMethod(LinearMethodBase):
             ops.silu_and_mul(out, y)
             return out
         return ops.pq_gemm_packed_silu_mul(x, packed, layer.codes, layer.codebooks, layer.scales, bias)
+
+
+# batch size up to which a format without an MFMA kernel stays on the generic fused kernel (the reference switches
+# from its gemv kernel to dequantise + GEMM above 6 tokens, aqlm.py:344-349)
+GENERIC_KERNEL_MAX_TOKENS = 8
 
 
 def register() -> None:
