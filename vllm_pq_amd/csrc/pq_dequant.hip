@@ -85,6 +85,75 @@ __global__ __launch_bounds__(DQ_THREADS) void dequant_vec8_kernel(
     }
 }
 
+// d = 8, one codebook: the bulk of the traffic of this format family.  A block owns DQ8_ROWS rows of one partition;
+// the codebook sits in LDS R times (lane l reads copy l mod R: no bank conflict whatever the codes are); a wave
+// step covers 256 consecutive groups of a row: four code loads of 64 consecutive codes, four gathers, four 16-byte
+// stores of one contiguous KiB each, non-temporal (the output is a stream nobody in this kernel reads back).
+constexpr int DQ8_ROWS = 16;
+constexpr int DQ8_MAX_R = 4;     // copies of the codebook in LDS: 16 KiB at K = 256, eight blocks per CU
+template <typename AT, typename CodeT>
+__global__ __launch_bounds__(DQ_THREADS) void dequant_d8_kernel(
+    const CodeT *__restrict__ codes, const uint16_t *__restrict__ codebooks, const uint16_t *__restrict__ scales,
+    TileMap tmap, int G, int K, int R, uint16_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const TileLoc loc = locate_tile(tmap, blockIdx.x, DQ8_ROWS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t kmask = (uint32_t)K - 1u;
+    {   // image: entry e, copy r at (e * R + r) * 16
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(codebooks + (size_t)loc.part * K * 8);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
+        const int slots = K * R;
+        const int rshift = __builtin_ctz((unsigned)R);
+        for (int i = tid; i < slots; i += DQ_THREADS) dst[i] = src[i >> rshift];
+        __syncthreads();
+    }
+    const uint32_t lane_off = (uint32_t)(lane & (R - 1)) * 16u;
+    const uint32_t eshift = 4 + __builtin_ctz((unsigned)R);
+    const int Kin = G * 8;
+    const int spans = (G + 255) / 256;                  // 256-group spans per row
+    const int total = loc.nrows * spans;
+    // the codes of the wave's next step are requested before the current one is gathered and stored
+    auto load_step = [&](int w, uint32_t (&c4)[4], float &s) {
+        const int wc = w < total ? w : total - 1;           // past the end: re-read the last step, never stored
+        const int r = wc / spans, sp = wc - r * spans;
+        const int n = loc.row0 + r;
+        const int g0 = sp * 256;
+        const CodeT *crow = codes + (size_t)n * G + g0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = 64 * j + lane;                    // store j writes pieces 64 j .. 64 j + 63: one contiguous KiB
+            c4[j] = code_index(crow[g0 + g < G ? g : G - 1 - g0], kmask);   // clamped at the row's end, not stored
+        }
+        s = scales ? Act<AT>::to_f32(scales[n]) : 1.f;
+    };
+    uint32_t cur[4], nxt[4];
+    float s_cur, s_nxt;
+    load_step(wave, cur, s_cur);
+    for (int w = wave; w < total; w += DQ_THREADS / 64) {
+        load_step(w + DQ_THREADS / 64, nxt, s_nxt);
+        const int r = w / spans, sp = w - r * spans;
+        const int n = loc.row0 + r;
+        const int g0 = sp * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x4 e = *reinterpret_cast<const u32x4 *>(smem + ((size_t)cur[j] << eshift) + lane_off);
+            if (scales) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint16_t lo = Act<AT>::from_f32(Act<AT>::to_f32((uint16_t)e[k]) * s_cur);
+                    const uint16_t hi = Act<AT>::from_f32(Act<AT>::to_f32((uint16_t)(e[k] >> 16)) * s_cur);
+                    e[k] = lo | ((uint32_t)hi << 16);
+                }
+            }
+            const int g = g0 + 64 * j + lane;
+            if (g < G) __builtin_nontemporal_store(e, reinterpret_cast<u32x4 *>(out + (size_t)n * Kin + (size_t)g * 8));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+        s_cur = s_nxt;
+    }
+}
+
 // Any d, any Kin: one output element per thread-step.
 template <typename AT, typename CodeT>
 __global__ __launch_bounds__(DQ_THREADS) void dequant_elem_kernel(
@@ -134,6 +203,14 @@ static hipError_t launch_dequant_t(const DequantArgs &a, hipStream_t stream) {
     }
     const bool use_lds = cb_bytes <= (size_t)DQ_LDS_BYTES && (cb_bytes % 16 == 0) &&
                          ((reinterpret_cast<uintptr_t>(cb) & 15) == 0);
+    if (a.d == 8 && a.M == 1 && use_lds) {
+        int R = DQ8_MAX_R;
+        while (R > 1 && cb_bytes * R > (size_t)DQ_LDS_BYTES / 4) R >>= 1;
+        const int tiles8 = tiles_in(a.parts, DQ8_ROWS);
+        hipLaunchKernelGGL((dequant_d8_kernel<AT, CodeT>), dim3(tiles8), dim3(DQ_THREADS), cb_bytes * R, stream, codes,
+                           cb, sc, make_tile_map(a.parts, DQ8_ROWS), a.G, a.K, R, out);
+        return hipGetLastError();
+    }
     const size_t lds = use_lds ? cb_bytes : 0;
 #define PQ_DQ_LAUNCH(DD, LL)                                                                                    \
     hipLaunchKernelGGL((dequant_vec8_kernel<AT, CodeT, DD, LL>), dim3(tiles), dim3(DQ_THREADS), lds, stream, codes, \
