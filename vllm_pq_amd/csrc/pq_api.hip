@@ -210,7 +210,7 @@ int pq_repack_codes(const void *codes, const int32_t *part_sizes, int32_t num_pa
     if (!codes || !packed_codes) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_repack_codes: NULL tensor pointer");
     if (reinterpret_cast<uintptr_t>(packed_codes) & 15)
         return fail(PQ_ERR_INVALID_ARGUMENT, "pq_repack_codes: packed_codes must be 16-byte aligned");
-    hipError_t e = pq::launch_repack(codes, N, G, M, d, code_bytes, packed_codes, static_cast<hipStream_t>(stream));
+    hipError_t e = pq::launch_repack(codes, N, G, M, K, d, code_bytes, packed_codes, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "pq_repack_codes: %s", hipGetErrorString(e));
     return PQ_OK;
 }

@@ -248,7 +248,7 @@ size_t packed_bytes(int N, int G, int M, int code_bytes) {
 
 template <typename CodeT>
 __global__ __launch_bounds__(256) void repack_kernel(const CodeT *__restrict__ codes, int N, int G, int M, int d,
-                                                     int nchunks, CodeT *__restrict__ packed) {
+                                                     int nchunks, uint32_t kmask, CodeT *__restrict__ packed) {
     constexpr int CPL = 16 / sizeof(CodeT);
     const int gpl = CPL / M;          // groups per lane
     const int cg = 4 * gpl;           // groups per chunk
@@ -267,14 +267,14 @@ __global__ __launch_bounds__(256) void repack_kernel(const CodeT *__restrict__ c
         const int gi = i / M;                   // group slot within the lane: s*cps + u
         const int s = gi / cps, u = gi % cps;
         const int g = c * cg + 4 * cps * s + cps * q + u;
-        out[i] = g < G ? codes[(n * G + g) * M + m] : (CodeT)0;
+        out[i] = g < G ? (CodeT)code_index(codes[(n * G + g) * M + m], kmask) : (CodeT)0;   // stored as the index, mod K
     }
     CodeT *dst = packed + (piece * 64 + lane) * CPL;
 #pragma unroll
     for (int i = 0; i < CPL; ++i) dst[i] = out[i];
 }
 
-hipError_t launch_repack(const void *codes, int N, int G, int M, int d, int code_bytes, void *packed,
+hipError_t launch_repack(const void *codes, int N, int G, int M, int K, int d, int code_bytes, void *packed,
                          hipStream_t stream) {
     const int cg = chunk_groups(code_bytes, M);
     const int nchunks = (G + cg - 1) / cg;
@@ -283,10 +283,10 @@ hipError_t launch_repack(const void *codes, int N, int G, int M, int d, int code
     const dim3 grid((unsigned)((npieces + 3) / 4));
     if (code_bytes == 1)
         hipLaunchKernelGGL(repack_kernel<int8_t>, grid, dim3(256), 0, stream, static_cast<const int8_t *>(codes), N, G,
-                           M, d, nchunks, static_cast<int8_t *>(packed));
+                           M, d, nchunks, (uint32_t)K - 1u, static_cast<int8_t *>(packed));
     else
         hipLaunchKernelGGL(repack_kernel<int16_t>, grid, dim3(256), 0, stream, static_cast<const int16_t *>(codes), N,
-                           G, M, d, nchunks, static_cast<int16_t *>(packed));
+                           G, M, d, nchunks, (uint32_t)K - 1u, static_cast<int16_t *>(packed));
     return hipGetLastError();
 }
 

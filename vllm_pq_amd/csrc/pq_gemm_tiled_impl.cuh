@@ -53,6 +53,19 @@ __device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
     return v;
 }
 
+// LDS address of this lane's copy of the d = 8 codebook entry that code `i` of a code piece selects.  One-byte
+// codes (K <= 256) always get 16 copies, 256 bytes per entry; they are stored reduced mod K in the packed layout
+// and the image starts at a multiple of 64 KiB, so the address is the code byte dropped into bits 8..15 of the
+// lane's offset: one v_perm_b32 instead of a bit-field extract and a shift-add.
+template <int CB, typename VecT>
+__device__ __forceinline__ uint32_t gather_addr8(const VecT &w, int i, uint32_t nbits, uint32_t shift, uint32_t img_lane) {
+    if constexpr (CB == 1) {
+        return __builtin_amdgcn_perm(w[i >> 2], img_lane, 0x0c0c0000u | ((4u + (uint32_t)(i & 3)) << 8));
+    } else {
+        return img_lane + (code_at<CB>(w, i, nbits) << shift);
+    }
+}
+
 constexpr int TL_THREADS = 512;
 constexpr int TL_WAVES = 8;
 constexpr int TL_BK = 64;    // k per LDS tile
@@ -67,8 +80,8 @@ __device__ inline uint32_t xt_off(int row, int slot) { return (uint32_t)row * 12
 // ABL (diagnostic builds only; 0 in the library): bit 0 skips the LDS store of the next tile and the
 // barrier, bit 1 the activation loads, bit 2 the epilogue stores, bit 3 the gathers, bit 4 the activation
 // fragment reads from LDS.
-template <typename AT, typename CodeT, int D, int M, int WAVES_T, int WN, int WT, int KT, int ABL = 0>
-__global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
+template <typename AT, typename CodeT, int D, int M, int WAVES_T, int WN, int WT, int KT, int ABL = 0, int NWV = TL_WAVES>
+__global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
     const uint16_t *__restrict__ x, int T, int64_t x_stride, const u32x4 *__restrict__ packed,
     const uint16_t *__restrict__ codebooks, const uint16_t *__restrict__ scales, const uint16_t *__restrict__ bias,
     TileMap tmap, int G, int K, int nbits, int R, uint16_t *__restrict__ y, int64_t y_stride, int n_tiles,
@@ -78,13 +91,13 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     constexpr int CB = sizeof(CodeT);
     constexpr int EB = 2 * D;
     constexpr int CG = F::CG, KS = F::KS, CPS = F::CPS;
-    constexpr int WAVES_N = TL_WAVES / WAVES_T;
+    constexpr int WAVES_N = NWV / WAVES_T;
     constexpr int BN = WAVES_N * WN * 16;            // weight rows per block
     constexpr int BT = WAVES_T * WT * 16;            // tokens per block
     constexpr int XT_BYTES = BT * TL_BK * 2;         // one activation tile
     constexpr int STAGE_BYTES = KT * XT_BYTES;       // one ring stage: KT consecutive tiles
     constexpr int NBUF = 3;                          // ring stages: one being read, two in flight
-    constexpr int PPW = BT / 64;                     // one-KiB pieces per wave per tile
+    constexpr int PPW = BT / (8 * NWV);              // one-KiB pieces per wave per tile
     // The codes of a chunk are consumed in PIECES register pieces (a half or a quarter of a lane's 16
     // bytes), so that the next ones can be prefetched with few live registers.
     constexpr int SPP = KS >= 8 ? KS / 4 : KS >= 4 ? KS / 2 : KS;   // k-steps per code piece
@@ -113,6 +126,17 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     const int q = lane >> 4;
     const int wn = wave / WAVES_T;                   // wave's position along n
     const int wt = wave % WAVES_T;                   // and along t
+    // ABL bit 5 (diagnostic builds): `bias` is a buffer of 8 wall-clock stamps per block instead of a bias
+    auto stamp = [&](int k) {
+        if constexpr (ABL & 32) {
+            if (tid == 0) {
+                unsigned long long *st = reinterpret_cast<unsigned long long *>(const_cast<uint16_t *>(bias)) + (size_t)blockIdx.x * 8;
+                st[k] = wall_clock64();
+                if (k == 1 || k == 2) st[k + 4] = __builtin_amdgcn_s_memtime();   // shader clock around the main loop
+            }
+        }
+    };
+    stamp(0);
 
     // ---- XCD-aware tile assignment --------------------------------------------------------------
     const int total = n_tiles * t_tiles;
@@ -238,7 +262,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
 
     // ---- codebook image ---------------------------------------------------------------------------
     {
-        CodebookImage<D, TL_THREADS> img;
+        CodebookImage<D, NWV * 64> img;
         img.load(reinterpret_cast<const unsigned char *>(codebooks) + (size_t)loc.part * M * K * EB, M * K, R, tid);
         img.store(smem, M * K, R, tid);
     }
@@ -266,6 +290,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     landed(c0);
     landed(c1);
     __syncthreads();
+    stamp(1);
 
     // Loop step u of U tiles: request the codes of a later step, then per ring stage: issue the DMA of
     // stage st+2, compute stage st, wait until only what was issued after the DMA of stage st+1 is
@@ -288,12 +313,12 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
             x_issue(u * SPU + sg + 2, buf2);
             if constexpr (PIPE) {
                 // One stage = NKS k-steps x NPAIR fragment pairs = NG groups of 2 gathers + 2*WT MFMAs, software-
-                // pipelined by hand: the gathers of group g+1 are issued before the MFMAs of group g, and the
-                // activation fragments of the next k-step are re-read right behind their last use in the last
-                // group of a k-step.  LDS reads return in order, so `lgkmcnt(n)` = all but the n newest.
-                constexpr int NKS = KT * 2, NPAIR = WN / 2, NG = NKS * NPAIR, H = WT / 2;
+                // pipelined by hand: the gathers of group g+2 are issued before the MFMAs of group g (three
+                // register sets), and the activation fragments of k-step kk+1 before the first MFMA of k-step kk
+                // (two sets).  LDS reads return in order, so `lgkmcnt(n)` = all but the n newest.
+                constexpr int NKS = KT * 2, NPAIR = WN / 2, NG = NKS * NPAIR;
                 const uint32_t xs0 = xlane[0] + (uint32_t)buf * STAGE_BYTES, xs1 = xlane[1] + (uint32_t)buf * STAGE_BYTES;
-                u32x4 xfr[WT], P[2][2];
+                u32x4 xfr[2][WT], P[3][2];
                 auto gather_pair = [&](auto gc, u32x4 (&dst)[2]) {        // group gc -> its two weight fragments
                     constexpr int g = decltype(gc)::value, kk = g / NPAIR, pp = g % NPAIR;
                     constexpr int tt_in = kk / 2, ks = kk % 2;
@@ -301,58 +326,39 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
                     const int sidx = (tt % TPP) * 2 + ks;
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const uint32_t idx = code_at<CB>(cur[tt / TPP][2 * pp + e], sidx, (uint32_t)nbits);
-                        dst[e] = lds_read16<0>(img_lane + (idx << shift));
+                        dst[e] = lds_read16<0>(gather_addr8<CB>(cur[tt / TPP][2 * pp + e], sidx, (uint32_t)nbits, shift, img_lane));
                     }
                 };
-                auto read_x = [&](auto kc, auto jc) {                      // activation fragment j of k-step kk
-                    constexpr int kk = decltype(kc)::value, j = decltype(jc)::value;
-                    constexpr int off = (kk / 2) * XT_BYTES + j * 2048;
-                    xfr[j] = lds_read16<off>((kk % 2) ? xs1 : xs0);
+                auto read_x = [&](auto kc) {                               // the WT activation fragments of k-step kk
+                    constexpr int kk = decltype(kc)::value;
+                    static_for<WT>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        constexpr int off = (kk / 2) * XT_BYTES + j * 2048;
+                        xfr[kk & 1][j] = lds_read16<off>((kk % 2) ? xs1 : xs0);
+                    });
                 };
-                static_for<WT>([&](auto jc) { read_x(std::integral_constant<int, 0>{}, jc); });
+                // reads group h issues before its MFMAs: the next k-step's activations (first group of a k-step)
+                auto xr = [](int h) constexpr { return (h >= 0 && h % NPAIR == 0 && h / NPAIR + 1 < NKS) ? WT : 0; };
+                read_x(std::integral_constant<int, 0>{});
                 gather_pair(std::integral_constant<int, 0>{}, P[0]);
+                if constexpr (NG > 1) gather_pair(std::integral_constant<int, (NG > 1 ? 1 : 0)>{}, P[1]);
                 static_for<NG>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value, kk = g / NPAIR, pp = g % NPAIR, c = g & 1;
-                    constexpr bool more = g + 1 < NG;
-                    constexpr bool reload = pp == NPAIR - 1 && kk + 1 < NKS;   // last group of a k-step
-                    if constexpr (more) gather_pair(std::integral_constant<int, more ? g + 1 : g>{}, P[c ^ 1]);
-                    constexpr int newer = more ? 2 : 0;                         // reads issued after this group's operands
-                    auto mfmas = [&](int j0, int j1) {
-#pragma unroll
-                        for (int j = j0; j < j1; ++j)
-#pragma unroll
-                            for (int e = 0; e < 2; ++e)
-                                acc[2 * pp + e][j] = Act<AT>::mfma16(__builtin_bit_cast(vec8, P[c][e]),
-                                                                     __builtin_bit_cast(vec8, xfr[j]), acc[2 * pp + e][j]);
-                    };
-                    constexpr bool halves = pp == 0 && kk > 0;   // this k-step's activations were requested in two
-                                                                 // halves behind the previous group's MFMAs
-                    asm volatile("s_waitcnt lgkmcnt(%2)\n\t; PQL %0\n\t; PQL %1" : "+v"(P[c][0]), "+v"(P[c][1]) : "n"(newer + (halves ? H : 0)));
+                    constexpr int g = decltype(gc)::value, kk = g / NPAIR, pp = g % NPAIR, c = g % 3, xb = kk & 1;
+                    if constexpr (xr(g) > 0) read_x(std::integral_constant<int, (xr(g) > 0 ? kk + 1 : kk)>{});
+                    if constexpr (g + 2 < NG) gather_pair(std::integral_constant<int, (g + 2 < NG ? g + 2 : g)>{}, P[(g + 2) % 3]);
+                    // LDS reads return in order: everything but the reads issued after this group's operands
+                    constexpr int newer = (g + 1 < NG ? 2 : 0) + (g + 2 < NG ? 2 : 0) + xr(g) + (NPAIR > 1 ? xr(g - 1) : 0);
+                    asm volatile("s_waitcnt lgkmcnt(%2)\n\t; PQL %0\n\t; PQL %1" : "+v"(P[c][0]), "+v"(P[c][1]) : "n"(newer));
                     if constexpr (pp == 0) {
 #pragma unroll
-                        for (int j = 0; j < (halves ? H : WT); ++j) asm volatile("; PQL %0" : "+v"(xfr[j]));
+                        for (int j = 0; j < WT; ++j) asm volatile("; PQL %0" : "+v"(xfr[xb][j]));
                     }
-                    mfmas(0, H);
-                    if constexpr (reload) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        static_for<H>([&](auto jc) { read_x(std::integral_constant<int, reload ? kk + 1 : kk>{}, jc); });
-                    }
-                    if constexpr (halves) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        // newer than the second half: the next group's gathers and, if issued, the first half's re-reads
-                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(newer + (reload ? H : 0)));
 #pragma unroll
-                        for (int j = H; j < WT; ++j) asm volatile("; PQL %0" : "+v"(xfr[j]));
-                    }
-                    mfmas(H, WT);
-                    if constexpr (reload) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        static_for<H>([&](auto jc) {
-                            read_x(std::integral_constant<int, reload ? kk + 1 : kk>{},
-                                   std::integral_constant<int, decltype(jc)::value + H>{});
-                        });
-                    }
+                    for (int j = 0; j < WT; ++j)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            acc[2 * pp + e][j] = Act<AT>::mfma16(__builtin_bit_cast(vec8, P[c][e]),
+                                                                 __builtin_bit_cast(vec8, xfr[xb][j]), acc[2 * pp + e][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             } else if constexpr (BATCH) {
@@ -378,8 +384,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
                         });
 #pragma unroll
                         for (int i = 0; i < WN; ++i) {
-                            const uint32_t idx = code_at<CB>(cur[tt / TPP][i], sidx, (uint32_t)nbits);
-                            ar[slot][kb][i] = lds_read16<0>(img_lane + (idx << shift));
+                            ar[slot][kb][i] = lds_read16<0>(gather_addr8<CB>(cur[tt / TPP][i], sidx, (uint32_t)nbits, shift, img_lane));
                         }
                     });
                 };
@@ -493,6 +498,7 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     }
     // every step above ended with its code loads landed; the activation DMA of the stages past the end may
     // still be writing LDS, which nothing below reads
+    stamp(2);
 
     // ---- epilogue: scale, bias, round, store ---------------------------------------------------------------
     // A lane holds 4 consecutive rows (8 bytes of y) of one token per fragment.  Fragments are taken in
@@ -500,14 +506,23 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
     // other, after which every lane owns 8 consecutive rows of one token (k-quad q even: rows 4q..4q+7 of
     // the pair's first fragment; q odd: rows 4(q-1)..+7 of the second), stored as 16 bytes -- half the
     // store instructions, 64 contiguous bytes per token and instruction instead of 32.
-    auto finish = [&](int i, int j, uint32_t &lo, uint32_t &hi) {   // fragment (i, j) -> two packed dwords
+    // The scales (and bias) of the lane's four rows of every fragment are 8 contiguous bytes: one load each, all
+    // requested before the first is used (one memory round trip for the whole epilogue).  Rows of a fragment are
+    // whole or absent (partition sizes are multiples of 16); an absent fragment reads the partition's last rows.
+    u32x2 sraw[WN], braw[WN];
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
         const int nb = loc.row0 + (wn * WN + i) * 16 + q * 4;
+        const int nc = nb + 4 <= row_end ? nb : row_end - 4;
+        sraw[i] = *reinterpret_cast<const u32x2 *>(scales + nc);
+        braw[i] = (bias && !(ABL & 32)) ? *reinterpret_cast<const u32x2 *>(bias + nc) : u32x2{0u, 0u};
+    }
+    auto finish = [&](int i, int j, uint32_t &lo, uint32_t &hi) {   // fragment (i, j) -> two packed dwords
         uint16_t h[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = nb + r < row_end ? nb + r : row_end - 1;
-            const float sc = Act<AT>::to_f32(scales[n]);
-            const float bi = bias ? Act<AT>::to_f32(bias[n]) : 0.f;
+            const float sc = Act<AT>::to_f32((uint16_t)(sraw[i][r >> 1] >> ((r & 1) * 16)));
+            const float bi = (bias && !(ABL & 32)) ? Act<AT>::to_f32((uint16_t)(braw[i][r >> 1] >> ((r & 1) * 16))) : 0.f;
             h[r] = Act<AT>::from_f32(acc[i][j][r] * sc + bi);
         }
         lo = h[0] | ((uint32_t)h[1] << 16);
@@ -570,6 +585,11 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_tiled_kernel(
                 }
             }
         }
+    }
+    if constexpr (ABL & 32) {
+        stamp(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(4);
     }
 }
 

@@ -66,7 +66,7 @@ hipError_t launch_gemm_stream_act(const GemmArgs &a, hipStream_t stream);
 bool stream_format_supported(int d, int K, int M, int code_bytes);
 bool packable(const Parts &parts, int d, int K, int M, int code_bytes);
 size_t packed_bytes(int N, int G, int M, int code_bytes);
-hipError_t launch_repack(const void *codes, int N, int G, int M, int d, int code_bytes, void *packed,
+hipError_t launch_repack(const void *codes, int N, int G, int M, int K, int d, int code_bytes, void *packed,
                          hipStream_t stream);
 
 // Fused gather + MFMA, LDS-tiled activations (large T).
