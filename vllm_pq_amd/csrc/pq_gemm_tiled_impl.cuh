@@ -66,6 +66,28 @@ __device__ __forceinline__ uint32_t gather_addr8(const VecT &w, int i, uint32_t 
     }
 }
 
+// The hand-pipelined stage issues its LDS reads in this order: activations of k-step 0, gathers of groups 0 and 1;
+// then group h (before and between its MFMAs): gathers of group h+2, activations of the next k-step when h is the
+// first group of a k-step.  LDS reads return in order; this is the number of reads issued after the last one
+// group g's MFMAs need (its gathers and, for the first group of a k-step, that k-step's activations) and before
+// group g's wait: the n of its `s_waitcnt lgkmcnt(n)`.
+template <int NG, int NPAIR, int NKS, int WT>
+constexpr int pipe_newer(int g) {
+    const int kk = g / NPAIR;
+    const bool need_x = g % NPAIR == 0;
+    int after = 0;          // reads issued after the last needed one so far
+    // prologue: X(0), G(0), G(1)
+    if (need_x && kk == 0) after = 0;
+    if (g == 0) after = 0;
+    else after += 2;        // G(0) is newer than X(0); not needed unless g == 0
+    if (NG > 1) { if (g == 1) after = 0; else after += 2; }
+    for (int h = 0; h < g; ++h) {
+        if (h + 2 < NG) { if (h + 2 == g) after = 0; else after += 2; }
+        if (h % NPAIR == 0 && h / NPAIR + 1 < NKS) { if (need_x && h / NPAIR + 1 == kk) after = 0; else after += WT; }
+    }
+    return after;
+}
+
 constexpr int TL_THREADS = 512;
 constexpr int TL_WAVES = 8;
 constexpr int TL_BK = 64;    // k per LDS tile
@@ -188,6 +210,15 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                     (const __attribute__((address_space(1))) void *)(xbase + (goff[j] + kb + it * (TL_BK * 2))),
                     (__attribute__((address_space(3))) void *)(dst + it * XT_BYTES + j * 1024), 16, 0, 0);
     };
+    // one of the KT * PPW wave-instructions of x_issue: piece j of tile `it` of the stage
+    auto x_issue_one = [&](int st, int buf, int it, int j) {
+        if constexpr (ABL & 2) return;
+        const uint32_t kb = (uint32_t)(st < nstages ? st : nstages - 1) * (KT * TL_BK * 2);
+        unsigned char *dst = xt + buf * STAGE_BYTES + wave * (PPW * 1024);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(xbase + (goff[j] + kb + it * (TL_BK * 2))),
+            (__attribute__((address_space(3))) void *)(dst + it * XT_BYTES + j * 1024), 16, 0, 0);
+    };
     x_issue(0, 0);
     x_issue(1, 1);
 
@@ -225,6 +256,19 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                 }
             }
         }
+    };
+    // load k of load_pieces' PPU * WN * PW, in its order
+    auto load_piece_one = [&](piece_t (&dst)[PPU][WN], int u, auto kc) {
+        constexpr int k = decltype(kc)::value, pi = k / (WN * PW), i = (k / PW) % WN, w = k % PW;
+        const int p = u * PPU + pi;
+        const uint32_t off =
+            (uint32_t)(p / PIECES) * 1024u + (uint32_t)lane * 16u + (uint32_t)(p % PIECES) * (16u / PIECES);
+        uint32_t t;
+        if constexpr (w == 0) asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
+        else if constexpr (w == 1) asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2 offset:4" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
+        else if constexpr (w == 2) asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2 offset:8" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
+        else asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2 offset:12" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
+        dst[pi][i][w] = t;
     };
     constexpr int CL = PPU * WN * PW;                // code loads per loop step
     constexpr bool DEEP = KT > 1 && CL <= 8;         // prefetch codes two steps ahead (three register sets)
@@ -307,11 +351,21 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
     auto step = [&](const piece_t (&cur)[PPU][WN], piece_t (&lands)[PPU][WN], piece_t (&req)[PPU][WN], int u, auto own_c) {
         constexpr bool own = decltype(own_c)::value;
         constexpr int AHEAD = DEEP ? 2 : 1;
-        load_pieces(req, u + AHEAD < nsteps ? u + AHEAD : nsteps - 1);
-#pragma unroll
-        for (int sg = 0; sg < SPU; ++sg) {
-            x_issue(u * SPU + sg + 2, buf2);
+        const int ureq = u + AHEAD < nsteps ? u + AHEAD : nsteps - 1;
+        if constexpr (!PIPE) load_pieces(req, ureq);
+        static_for<SPU>([&](auto sgc) {
+            constexpr int sg = decltype(sgc)::value;
+            if constexpr (!PIPE) x_issue(u * SPU + sg + 2, buf2);
             if constexpr (PIPE) {
+                // The stage's global-memory requests -- in a step's first stage the code loads, then the activation
+                // DMA of stage st+2 -- go out one or two at a time behind the last MFMA of each group instead of in
+                // one burst at the head of the stage; codes first, so that they are older than the stage's DMA.
+                constexpr int NCODE = sg == 0 ? CL : 0, NOPS = NCODE + KT * PPW;
+                auto vm_op = [&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (k < NCODE) load_piece_one(req, ureq, kc);
+                    else x_issue_one(u * SPU + sg + 2, buf2, (k - NCODE) / PPW, (k - NCODE) % PPW);
+                };
                 // One stage = NKS k-steps x NPAIR fragment pairs = NG groups of 2 gathers + 2*WT MFMAs, software-
                 // pipelined by hand: the gathers of group g+2 are issued before the MFMAs of group g (three
                 // register sets), and the activation fragments of k-step kk+1 before the first MFMA of k-step kk
@@ -344,22 +398,41 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                 if constexpr (NG > 1) gather_pair(std::integral_constant<int, (NG > 1 ? 1 : 0)>{}, P[1]);
                 static_for<NG>([&](auto gc) {
                     constexpr int g = decltype(gc)::value, kk = g / NPAIR, pp = g % NPAIR, c = g % 3, xb = kk & 1;
-                    if constexpr (xr(g) > 0) read_x(std::integral_constant<int, (xr(g) > 0 ? kk + 1 : kk)>{});
-                    if constexpr (g + 2 < NG) gather_pair(std::integral_constant<int, (g + 2 < NG ? g + 2 : g)>{}, P[(g + 2) % 3]);
-                    // LDS reads return in order: everything but the reads issued after this group's operands
-                    constexpr int newer = (g + 1 < NG ? 2 : 0) + (g + 2 < NG ? 2 : 0) + xr(g) + (NPAIR > 1 ? xr(g - 1) : 0);
+                    constexpr bool G2 = g + 2 < NG, XR = xr(g) > 0;
+                    constexpr int g2 = G2 ? g + 2 : g, kk2 = g2 / NPAIR, pp2 = g2 % NPAIR;
+                    constexpr int newer = pipe_newer<NG, NPAIR, NKS, WT>(g);
                     asm volatile("s_waitcnt lgkmcnt(%2)\n\t; PQL %0\n\t; PQL %1" : "+v"(P[c][0]), "+v"(P[c][1]) : "n"(newer));
                     if constexpr (pp == 0) {
 #pragma unroll
                         for (int j = 0; j < WT; ++j) asm volatile("; PQL %0" : "+v"(xfr[xb][j]));
                     }
+                    // the group's 2*WT MFMAs with its LDS traffic spread over the gaps between them, one or two
+                    // instructions a gap: both gather addresses, the two gathers, then the next k-step's activations
+                    uint32_t ga[2] = {0u, 0u};
+                    static_for<2 * WT>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value, j = m / 2, e = m % 2;
+                        acc[2 * pp + e][j] = Act<AT>::mfma16(__builtin_bit_cast(vec8, P[c][e]),
+                                                             __builtin_bit_cast(vec8, xfr[xb][j]), acc[2 * pp + e][j]);
+                        if constexpr (G2 && m == 0) {
+                            const int tt = sg * KT + kk2 / 2;
+                            const int sidx = (tt % TPP) * 2 + kk2 % 2;
 #pragma unroll
-                    for (int j = 0; j < WT; ++j)
-#pragma unroll
-                        for (int e = 0; e < 2; ++e)
-                            acc[2 * pp + e][j] = Act<AT>::mfma16(__builtin_bit_cast(vec8, P[c][e]),
-                                                                 __builtin_bit_cast(vec8, xfr[xb][j]), acc[2 * pp + e][j]);
-                    __builtin_amdgcn_sched_barrier(0);
+                            for (int e2 = 0; e2 < 2; ++e2)
+                                ga[e2] = gather_addr8<CB>(cur[tt / TPP][2 * pp2 + e2], sidx, (uint32_t)nbits, shift, img_lane);
+                        }
+                        if constexpr (G2 && (m == 1 || m == 2)) P[g2 % 3][m - 1] = lds_read16<0>(ga[m - 1]);
+                        if constexpr (XR && m >= 3 && m - 3 < WT) {
+                            constexpr int jx = m - 3, kx = XR ? kk + 1 : kk;
+                            constexpr int off = (kx / 2) * XT_BYTES + jx * 2048;
+                            xfr[kx & 1][jx] = lds_read16<off>((kx % 2) ? xs1 : xs0);
+                        }
+                        if constexpr (m == 2 * WT - 1) {
+                            constexpr int k0 = g * NOPS / NG, k1 = (g + 1) * NOPS / NG;
+                            static_for<k1 - k0>([&](auto dc) { vm_op(std::integral_constant<int, k0 + decltype(dc)::value>{}); });
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    static_assert(3 + WT <= 2 * WT, "not enough MFMA gaps for the group's reads");
                 });
             } else if constexpr (BATCH) {
                 // Few MFMAs per k-step (small tiles): the operands of NB k-steps are requested in one go and
@@ -473,7 +546,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
             }
             buf = buf == NBUF - 1 ? 0 : buf + 1;
             buf2 = buf2 == NBUF - 1 ? 0 : buf2 + 1;
-        }
+        });
     };
     constexpr std::integral_constant<bool, false> keep{};   // the request stays in flight into the next step
     constexpr std::integral_constant<bool, true> land{};    // nothing in flight when the step ends
