@@ -102,7 +102,7 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 def test_kernels_do_not_spill_registers():
     """The MFMA kernels hold inline-asm loads in flight in registers the compiler does not track; a spill could save
     such a register before its load has returned.  `make check-spills` compiles the kernel translation units to
-    assembly (cached under csrc/build) and fails on any non-zero spill count."""
+    assembly (cached under csrc/build) and fails on any non-zero vector-register spill count."""
     import shutil
     import subprocess
     hipcc = "/opt/rocm/bin/hipcc"

@@ -285,6 +285,29 @@ def test_tiled_kernel_every_tile_shape(ops, monkeypatch, cfg, dtype):
     assert_close_to_exact(bits_of(y), y32, dtype, f"tiled cfg {cfg}")
 
 
+@pytest.mark.parametrize("slots", [1, 2, 3])
+@pytest.mark.parametrize("cfg,fmt", [(5, (256, 8, 1)), (2, (256, 8, 1)), (4, (256, 8, 1)), (5, (256, 4, 1)),
+                                     (2, (256, 8, 2)), (5, (4096, 8, 1))])
+def test_tiled_kernel_blocks_walk_several_tiles(ops, monkeypatch, slots, cfg, fmt):
+    """A block of the tiled kernel takes every `8 * slots`-th tile of its run: with few blocks each one computes
+    several tiles in a row, across token tiles, row tiles and partitions (codebook image rebuilt in between, ring
+    position and code registers carried over).  Same bits as with one tile per block."""
+    K, d, M = fmt
+    parts, Kin, T = [208, 64, 144], 1024, 330
+    p = Problem(900 + cfg, K, d, M, parts, Kin, T, "bf16", bias=True).to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    assert packed is not None
+    monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "tiled")
+    monkeypatch.setenv("PQ_AMD_TILED_CFG", str(cfg))
+    monkeypatch.setenv("PQ_AMD_TILED_SLOTS", "100000")
+    y1 = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    monkeypatch.setenv("PQ_AMD_TILED_SLOTS", str(slots))
+    y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    assert torch.equal(y, y1)
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(y), y32, "bf16", f"K={K} d={d} M={M} cfg {cfg} slots {slots}")
+
+
 @pytest.mark.parametrize("fmt", [(256, 4, 1), (16, 2, 1), (4096, 8, 1), (256, 8, 2)])
 @pytest.mark.parametrize("cfg", [0, 2, 5, 6])
 def test_tiled_kernel_other_formats_tile_shapes(ops, monkeypatch, fmt, cfg):

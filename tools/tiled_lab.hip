@@ -9,6 +9,7 @@
 #include "pq_gemm_tiled_impl.cuh"
 
 using namespace pq;
+static int g_slots = 32;   // blocks per XCD (32 CUs each); a large value gives one tile per block
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <int WAVES_T, int WN, int WT, int KT, int ABL, int NWV = 8>
@@ -41,14 +42,14 @@ float run(const char *label, int T, int N, int G, int nparts) {
     }
     const int R = stream_replication<D>(K, M);
     const int n_tiles = tiles_in(parts, BN), t_tiles = (T + BT - 1) / BT;
-    const int per_xcd = (n_tiles * t_tiles + 7) / 8;
+    const int per_xcd = (n_tiles * t_tiles + 7) / 8, nslots = per_xcd < g_slots ? per_xcd : g_slots;
     const size_t lds = (size_t)ST_MAX_LDS_CB + 3 * (size_t)KT * BT * TL_BK * 2;
     auto kern = gemm_tiled_kernel<bf16_t, int8_t, D, M, WAVES_T, WN, WT, KT, ABL, NWV>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto launch = [&]() {
-        hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(NWV * 64), lds, 0, (const uint16_t *)x, T, (int64_t)G * D,
+        hipLaunchKernelGGL(kern, dim3(nslots * 8), dim3(NWV * 64), lds, 0, (const uint16_t *)x, T, (int64_t)G * D,
                            (const u32x4 *)pk, (const uint16_t *)cb, (const uint16_t *)sc, (const uint16_t *)nullptr,
                            make_tile_map(parts, BN), G, K, 8, R, (uint16_t *)y, (int64_t)N, n_tiles, t_tiles);
     };
@@ -86,7 +87,7 @@ void stamps(int T, int N, int G, int nparts) {
     CK(hipMalloc(&y, (size_t)T * N * 2));
     const int R = stream_replication<D>(K, M);
     const int n_tiles = tiles_in(parts, BN), t_tiles = (T + BT - 1) / BT;
-    const int per_xcd = (n_tiles * t_tiles + 7) / 8, nblk = per_xcd * 8;
+    const int per_xcd = (n_tiles * t_tiles + 7) / 8, nslots = per_xcd < g_slots ? per_xcd : g_slots, nblk = nslots * 8;
     CK(hipMalloc(&st, (size_t)nblk * 64)); CK(hipMemset(st, 0, (size_t)nblk * 64));
     const size_t lds = (size_t)ST_MAX_LDS_CB + 3 * (size_t)KT * BT * TL_BK * 2;
     auto kern = gemm_tiled_kernel<bf16_t, int8_t, D, M, WAVES_T, WN, WT, KT, 32>;
@@ -113,7 +114,7 @@ void stamps(int T, int N, int G, int nparts) {
     unsigned long long t0 = ~0ull, t1 = 0;
     for (int b = 0; b < nblk; ++b) { t0 = std::min(t0, h[b * 8]); t1 = std::max(t1, h[b * 8 + 4]); }
     printf("tile %dx%d T=%d N=%d Kin=%d blocks=%d: first start .. last end %.2f us\n", BN, BT, T, N, G * D, nblk, (t1 - t0) / 100.0);
-    const char *names[] = {"prologue", "main loop", "epilogue issue", "stores drain", "whole block"};
+    const char *names[] = {"prologue", "first main loop", "first epilogue", "rest of block", "whole block"};
     for (int k = 0; k < 5; ++k) {
         std::vector<double> v;
         for (int b = 0; b < nblk; ++b) v.push_back(k < 4 ? (h[b * 8 + k + 1] - h[b * 8 + k]) / 100.0 : (h[b * 8 + 4] - h[b * 8]) / 100.0);
@@ -144,6 +145,7 @@ void stamps(int T, int N, int G, int nparts) {
 
 int main(int argc, char **argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 4096;
+    if (argc > 3) g_slots = atoi(argv[3]);
     if (argc > 2 && argv[2][0] == 's') {
         stamps<2, 8, 4, 2>(T, 28672, 512, 2);
         return 0;

@@ -21,7 +21,9 @@ bool gemm_tiled_supported(const GemmArgs &a) {
     }
     if ((reinterpret_cast<uintptr_t>(a.x) & 15) || (a.x_stride % 8)) return false;
     if ((reinterpret_cast<uintptr_t>(a.codes) & 15) || (reinterpret_cast<uintptr_t>(a.codebooks) & 15)) return false;
-    // the epilogue reads the scales and bias of four consecutive rows with one 8-byte load
+    // the epilogue stores 16 bytes (8 rows of one token) per lane
+    if ((reinterpret_cast<uintptr_t>(a.y) & 15) || (a.y_stride % 8)) return false;
+    // and reads the scales and bias of four consecutive rows with one 8-byte load
     if ((reinterpret_cast<uintptr_t>(a.scales) & 7) || (reinterpret_cast<uintptr_t>(a.bias) & 7)) return false;
     return true;
 }
