@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 --pmc counter_collection CSV: per kernel (name, grid) the mean of each counter."""
+"""Summarise a rocprofv3 --pmc counter_collection CSV: per kernel (name, grid) the mean, median and maximum of each
+counter.  The persistent tiled kernel launches one block per CU whatever the layer, so one (name, grid) key mixes
+layers; in the bench run most of its launches are the dominant layer's, whose value is the median."""
 import collections
 import csv
 import glob
@@ -18,4 +20,5 @@ for key, ctrs in agg.items():
         continue
     print(key)
     for c, v in sorted(ctrs.items()):
-        print(f"   {c:32s} n={len(v):4d} mean={sum(v)/len(v):16.1f}")
+        v = sorted(v)
+        print(f"   {c:32s} n={len(v):4d} mean={sum(v)/len(v):16.1f} median={v[len(v)//2]:16.1f} max={v[-1]:16.1f}")
