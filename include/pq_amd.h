@@ -65,6 +65,7 @@ typedef enum pq_status {
 #define PQ_CAP_FP16 (1ull << 5)
 #define PQ_CAP_ELEMENTWISE (1ull << 6) /* pq_silu_and_mul, pq_rms_norm, pq_fused_add_rms_norm */
 #define PQ_CAP_FUSED_SILU_MUL (1ull << 7) /* pq_gemm_packed_silu_mul runs fused for small batches */
+#define PQ_CAP_EMBEDDING (1ull << 8)      /* pq_embedding */
 
 /* Version of this ABI (PQ_ABI_VERSION) and capability bits.  No reference counterpart. */
 int pq_version(void);
@@ -83,6 +84,20 @@ const char *pq_last_error(void);
 int pq_dequant(const void *codes, const void *codebooks, const void *scales /* nullable */,
                const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K,
                int32_t d, int32_t code_bytes, int32_t dtype, void *out, void *stream);
+
+/*
+ * Rows of that weight picked by an index vector: out[t][:] = W[ids[t]][:] for t < T, ids int64 on the device,
+ * out rows out_row_stride elements apart.  Every element goes through pq_dequant's operations in its order, so
+ * the result equals indexing pq_dequant's output bit for bit.  An index outside [0, N) gives a row of zeros.
+ * It is QuantizeMethodBase.embedding (vllm/model_executor/layers/quantization/base_config.py:30-35), which
+ * VocabParallelEmbedding.forward calls with indices already masked into the rank's shard
+ * (vllm/model_executor/layers/vocab_parallel_embedding.py:403-422); the reference's unquantised method is
+ * F.embedding (same file :45-47), and its AQLM method has no embedding().
+ */
+int pq_embedding(const int64_t *ids, int32_t T, const void *codes, const void *codebooks,
+                 const void *scales /* nullable */, const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G,
+                 int32_t M, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype, void *out, int64_t out_row_stride,
+                 void *stream);
 
 /*
  * Bytes of scratch with which pq_gemm / pq_gemm_packed may spread the K range of an output tile over several

@@ -11,11 +11,12 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from oracle.torch_restatement import pq_linear_cpu
-from vllm_pq_amd import PQConfig, PQLinearMethod
+from oracle.torch_restatement import pq_linear_cpu, reconstruct_partition
+from vllm_pq_amd import PQConfig, PQEmbeddingMethod, PQLinearMethod
 from vllm_pq_amd.host import parallel_state as ps
 from vllm_pq_amd.host.linear import (ColumnParallelLinear, MergedColumnParallelLinear, QKVParallelLinear,
                                      RowParallelLinear)
+from vllm_pq_amd.host.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding, compute_logits
 
 
 class OraclePQMethod(PQLinearMethod):
@@ -26,9 +27,24 @@ class OraclePQMethod(PQLinearMethod):
                              layer.codebooks.output_partition_sizes, bias)
 
 
+class OraclePQEmbeddingMethod(PQEmbeddingMethod):
+    """The vocabulary-table method with the CPU oracle in place of both kernels."""
+
+    def apply(self, layer, x, bias=None):
+        return pq_linear_cpu(x, layer.codes, layer.codebooks, layer.scales, [layer.codes.shape[0]], bias)
+
+    def embedding(self, layer, input_):
+        return reconstruct_partition(layer.codes, layer.codebooks, layer.scales)[input_]
+
+
 class OraclePQConfig(PQConfig):
     def get_quant_method(self, layer, prefix):
+        if isinstance(layer, VocabParallelEmbedding):
+            return OraclePQEmbeddingMethod(self)
         return OraclePQMethod(self)
+
+
+VOCAB = 150      # padded to 192: 96 rows a rank, 42 of rank 1's are padding
 
 
 HID, INTER, HEADS, KV, HD, D = 64, 96, 4, 1, 16, 8
@@ -46,6 +62,8 @@ def full_weights():
     w = {name: mat(n, kin) for name, n, kin in (("q", HEADS * HD, HID), ("k", KV * HD, HID), ("v", KV * HD, HID),
                                                 ("o", HID, HEADS * HD), ("gate", INTER, HID), ("up", INTER, HID),
                                                 ("down", HID, INTER), ("col", 48, HID))}
+    w["vocab"] = mat(VOCAB, HID)
+    w["ids"] = torch.randint(0, VOCAB, (3, 7), generator=g)
     w["down_bias"] = torch.randn(HID, generator=g).to(DT)
     w["x"] = torch.randn(5, HID, generator=g).to(DT)
     return w
@@ -104,6 +122,17 @@ def worker(rank, world, port, out):
         load(col, w["col"])
         res["col_gathered"] = col(x)[0]
 
+        # vocabulary-parallel PQ table and head: ids of the other rank are masked out and the partial lookups summed
+        # (vocab_parallel_embedding.py:403-422); the head's shards are gathered and the padding cut off
+        emb = VocabParallelEmbedding(VOCAB, HID, DT, quant_config=cfg)
+        head = ParallelLMHead(VOCAB, HID, params_dtype=DT, quant_config=cfg)
+        for layer in (emb, head):
+            load(layer, w["vocab"])
+        assert emb.codes.shape[0] == 96
+        res["emb"] = emb(w["ids"])
+        res["logits_shard"] = head.quant_method.apply(head, x)
+        res["logits"] = compute_logits(head, x)
+
         # known-answer all-reduce, as the reference's comm-op test does (tests/distributed/test_comm_ops.py:30-38)
         t = torch.arange(8, dtype=torch.float32) * (rank + 1)
         res["allreduce"] = ps.tensor_model_parallel_all_reduce(t)
@@ -153,3 +182,13 @@ def test_two_rank_tensor_parallel_matches_unsharded(tmp_path):
         assert torch.equal(r[rank]["col_gathered"], dense(w["col"], x))
         assert torch.equal(r[rank]["allreduce"], torch.arange(8, dtype=torch.float32) * 3)
     assert torch.equal(r[0]["down"], r[1]["down"])
+
+    table = reconstruct_partition(w["vocab"]["codes"], w["vocab"]["codebooks"], w["vocab"]["scales"])
+    logits_full = dense(w["vocab"], x)
+    for rank in range(world):
+        assert torch.equal(r[rank]["emb"], table[w["ids"]])                  # exact: one rank's row plus zeros
+        lo, hi = 96 * rank, min(96 * (rank + 1), VOCAB)
+        assert torch.equal(r[rank]["logits_shard"][:, :hi - lo], logits_full[:, lo:hi])
+        assert not r[rank]["logits_shard"][:, hi - lo:].any()                # padding rows: zero scales
+        assert r[rank]["logits"].shape == (5, VOCAB)
+        assert torch.equal(r[rank]["logits"][:, :96], logits_full[:, :96])

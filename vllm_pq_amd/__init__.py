@@ -6,7 +6,7 @@ importable, with the stand-alone mirror otherwise).  All compute goes through li
 """
 from . import ops  # noqa: F401
 from .compat import HAVE_VLLM  # noqa: F401
-from .pq import (PQ_METHOD_NAME, PQConfig, PQLinearMethod, get_int_dtype, register,  # noqa: F401
+from .pq import (PQ_METHOD_NAME, PQConfig, PQEmbeddingMethod, PQLinearMethod, get_int_dtype, register,  # noqa: F401
                  unpack_int_data)
 
 register()

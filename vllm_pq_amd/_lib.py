@@ -17,7 +17,7 @@ PQ_DTYPE_FP16, PQ_DTYPE_BF16 = 0, 1
 # every symbol include/pq_amd.h declares
 EXPORTS = ("pq_version", "pq_caps", "pq_last_error", "pq_dequant", "pq_gemm_workspace_bytes", "pq_gemm",
            "pq_packed_codes_bytes", "pq_repack_codes", "pq_gemm_packed", "pq_gemm_kernel_name", "pq_silu_and_mul",
-           "pq_rms_norm", "pq_fused_add_rms_norm", "pq_gemm_silu_mul_is_fused", "pq_gemm_packed_silu_mul")
+           "pq_rms_norm", "pq_fused_add_rms_norm", "pq_gemm_silu_mul_is_fused", "pq_gemm_packed_silu_mul", "pq_embedding")
 
 _lock = threading.Lock()
 _lib = None
@@ -56,6 +56,8 @@ def load():
         L.pq_last_error.restype = ctypes.c_char_p
         L.pq_dequant.argtypes = [vp, vp, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
         L.pq_dequant.restype = ctypes.c_int
+        L.pq_embedding.argtypes = [vp, i32, vp, vp, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp]
+        L.pq_embedding.restype = ctypes.c_int
         L.pq_gemm_workspace_bytes.argtypes = [i32] * 8
         L.pq_gemm_workspace_bytes.restype = sz
         L.pq_gemm.argtypes = [vp, i32, i64, vp, vp, vp, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64,

@@ -5,6 +5,7 @@ try:  # pragma: no cover - vLLM is not installed in the build image
     from vllm.model_executor.layers.quantization import (QUANTIZATION_METHODS, get_quantization_config,
                                                          register_quantization_config)
     from vllm.model_executor.layers.quantization.base_config import QuantizationConfig, QuantizeMethodBase
+    from vllm.model_executor.layers.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding
     from vllm.model_executor.utils import set_weight_attrs
     HAVE_VLLM = True
 except Exception:  # ImportError, or a half-installed vLLM
@@ -12,7 +13,9 @@ except Exception:  # ImportError, or a half-installed vLLM
                                    get_quantization_config, register_quantization_config)
     from .host.linear import LinearBase, LinearMethodBase
     from .host.utils import set_weight_attrs
+    from .host.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding
     HAVE_VLLM = False
 
-__all__ = ["HAVE_VLLM", "LinearBase", "LinearMethodBase", "QUANTIZATION_METHODS", "QuantizationConfig",
+__all__ = ["HAVE_VLLM", "LinearBase", "LinearMethodBase", "ParallelLMHead", "VocabParallelEmbedding",
+           "QUANTIZATION_METHODS", "QuantizationConfig",
            "QuantizeMethodBase", "get_quantization_config", "register_quantization_config", "set_weight_attrs"]

@@ -98,7 +98,7 @@ int pq_version(void) { return PQ_ABI_VERSION; }
 
 uint64_t pq_caps(void) {
     return PQ_CAP_DEQUANT | PQ_CAP_GEMM | PQ_CAP_MFMA_SMALL_T | PQ_CAP_MFMA_TILED | PQ_CAP_BF16 | PQ_CAP_FP16 |
-           PQ_CAP_ELEMENTWISE | PQ_CAP_FUSED_SILU_MUL;
+           PQ_CAP_ELEMENTWISE | PQ_CAP_FUSED_SILU_MUL | PQ_CAP_EMBEDDING;
 }
 
 const char *pq_last_error(void) { return g_err; }
@@ -115,6 +115,23 @@ int pq_dequant(const void *codes, const void *codebooks, const void *scales, con
     a.N = N; a.G = G; a.M = M; a.K = K; a.d = d; a.code_bytes = code_bytes; a.dtype = dtype; a.out = out;
     hipError_t e = pq::launch_dequant(a, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "pq_dequant: %s", hipGetErrorString(e));
+    return PQ_OK;
+}
+
+int pq_embedding(const int64_t *ids, int32_t T, const void *codes, const void *codebooks, const void *scales,
+                 const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d,
+                 int32_t code_bytes, int32_t dtype, void *out, int64_t out_row_stride, void *stream) {
+    pq::DequantArgs a;
+    int rc = check_format("pq_embedding", part_sizes, num_parts, N, G, M, K, d, code_bytes, dtype, &a.parts);
+    if (rc) return rc;
+    if (T < 0) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_embedding: T=%d", T);
+    if (T == 0 || G == 0) return PQ_OK;
+    if (out_row_stride < (int64_t)G * d) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_embedding: out_row_stride %lld < %d features", (long long)out_row_stride, G * d);
+    if (!ids || !codes || !codebooks || !out) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_embedding: NULL tensor pointer");
+    a.codes = codes; a.codebooks = codebooks; a.scales = scales;
+    a.N = N; a.G = G; a.M = M; a.K = K; a.d = d; a.code_bytes = code_bytes; a.dtype = dtype; a.out = out;
+    hipError_t e = pq::launch_embed_rows(a, ids, T, out_row_stride, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "pq_embedding: %s", hipGetErrorString(e));
     return PQ_OK;
 }
 

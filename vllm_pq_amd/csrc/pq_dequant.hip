@@ -234,6 +234,104 @@ static hipError_t launch_dequant_t(const DequantArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// Rows of the reconstructed weight selected by an index vector: out[t][:] = W[ids[t]][:], the embedding lookup of
+// a PQ-compressed table (F.embedding over dequantize_weight's result; each element takes dequantize_weight's own
+// operations in its order: sum over the codebooks in fp32, one rounding, times the row's scale, one rounding).
+// One block per index; an index outside [0, N) gives a row of zeros (callers mask their indices into range).
+template <typename AT, typename CodeT>
+__global__ __launch_bounds__(DQ_THREADS) void embed_rows_kernel(
+    const int64_t *__restrict__ ids, const CodeT *__restrict__ codes, const uint16_t *__restrict__ codebooks,
+    const uint16_t *__restrict__ scales, Parts parts, int N, int G, int M, int K, int d, bool vec,
+    uint16_t *__restrict__ out, int64_t out_stride) {
+    const int t = blockIdx.x;
+    const int64_t n = ids[t];
+    const int Kin = G * d;
+    uint16_t *orow = out + (size_t)t * out_stride;
+    if (n < 0 || n >= N) {
+        for (int k = threadIdx.x; k < Kin; k += DQ_THREADS) orow[k] = 0;
+        return;
+    }
+    int part = 0, start = 0;
+#pragma unroll
+    for (int p = 0; p < PQ_MAX_PARTS; ++p) {
+        if (p + 1 < parts.num && n >= start + parts.size[p]) { start += parts.size[p]; part = p + 1; }
+    }
+    const uint32_t kmask = (uint32_t)K - 1u;
+    const uint16_t *cb = codebooks + (size_t)part * M * K * d;
+    const CodeT *crow = codes + (size_t)n * G * M;
+    const bool scaled = scales != nullptr;
+    const float s = scaled ? Act<AT>::to_f32(scales[n]) : 1.f;
+    auto element = [&](int k) -> uint16_t {
+        const int g = k / d, j = k - g * d;
+        uint16_t h;
+        if (M == 1) {
+            h = cb[(size_t)code_index(crow[g], kmask) * d + j];
+        } else {
+            float acc = 0.f;
+            for (int m = 0; m < M; ++m) acc += Act<AT>::to_f32(cb[((size_t)m * K + code_index(crow[g * M + m], kmask)) * d + j]);
+            h = Act<AT>::from_f32(acc);
+        }
+        if (scaled) h = Act<AT>::from_f32(Act<AT>::to_f32(h) * s);
+        return h;
+    };
+    if (vec && d == 8 && M == 1) {   // one code, one 16-byte codebook entry (L1/L2-resident), one 16-byte store
+        const bool cb_al = (reinterpret_cast<uintptr_t>(cb) & 15) == 0;
+        for (int c = threadIdx.x; c < G; c += DQ_THREADS) {
+            const uint16_t *e = cb + (size_t)code_index(crow[c], kmask) * 8;
+            u32x4 v;
+            if (cb_al) {
+                v = *reinterpret_cast<const u32x4 *>(e);
+            } else {
+                v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
+                v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+            }
+            if (scaled) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint16_t lo = Act<AT>::from_f32(Act<AT>::to_f32((uint16_t)v[k]) * s);
+                    const uint16_t hi = Act<AT>::from_f32(Act<AT>::to_f32((uint16_t)(v[k] >> 16)) * s);
+                    v[k] = lo | ((uint32_t)hi << 16);
+                }
+            }
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(orow + (size_t)c * 8));
+        }
+    } else if (vec) {   // 16 bytes per thread-step: Kin % 8 == 0 and 16-byte aligned rows, checked on the host
+        for (int c = threadIdx.x; c < Kin / 8; c += DQ_THREADS) {
+            uint16_t h[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = element(c * 8 + j);
+            u32x4 v;
+            v.x = h[0] | ((uint32_t)h[1] << 16);
+            v.y = h[2] | ((uint32_t)h[3] << 16);
+            v.z = h[4] | ((uint32_t)h[5] << 16);
+            v.w = h[6] | ((uint32_t)h[7] << 16);
+            *reinterpret_cast<u32x4 *>(orow + (size_t)c * 8) = v;
+        }
+    } else {
+        for (int k = threadIdx.x; k < Kin; k += DQ_THREADS) orow[k] = element(k);
+    }
+}
+
+hipError_t launch_embed_rows(const DequantArgs &a, const int64_t *ids, int T, int64_t out_stride, hipStream_t stream) {
+    if (T == 0 || a.G == 0) return hipSuccess;
+    const uint16_t *cb = static_cast<const uint16_t *>(a.codebooks);
+    const uint16_t *sc = static_cast<const uint16_t *>(a.scales);
+    uint16_t *out = static_cast<uint16_t *>(a.out);
+    const bool vec = ((a.G * a.d) % 8 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && (out_stride % 8 == 0);
+#define PQ_EMBED_LAUNCH(AT, CT)                                                                                     \
+    hipLaunchKernelGGL((embed_rows_kernel<AT, CT>), dim3(T), dim3(DQ_THREADS), 0, stream, ids,                      \
+                       static_cast<const CT *>(a.codes), cb, sc, a.parts, a.N, a.G, a.M, a.K, a.d, vec, out, out_stride)
+    if (a.dtype == PQ_DTYPE_BF16) {
+        if (a.code_bytes == 1) PQ_EMBED_LAUNCH(bf16_t, int8_t);
+        else PQ_EMBED_LAUNCH(bf16_t, int16_t);
+    } else {
+        if (a.code_bytes == 1) PQ_EMBED_LAUNCH(fp16_t, int8_t);
+        else PQ_EMBED_LAUNCH(fp16_t, int16_t);
+    }
+#undef PQ_EMBED_LAUNCH
+    return hipGetLastError();
+}
+
 hipError_t launch_dequant(const DequantArgs &a, hipStream_t stream) {
     if (a.dtype == PQ_DTYPE_BF16) {
         return a.code_bytes == 1 ? launch_dequant_t<bf16_t, int8_t>(a, stream)

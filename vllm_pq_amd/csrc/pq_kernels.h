@@ -35,6 +35,7 @@ struct GemmArgs {
 };
 
 hipError_t launch_dequant(const DequantArgs &a, hipStream_t stream);
+hipError_t launch_embed_rows(const DequantArgs &a, const int64_t *ids, int T, int64_t out_stride, hipStream_t stream);
 
 // Any format: one wave per output row, VALU dot products.  Always available.
 hipError_t launch_gemm_generic(const GemmArgs &a, hipStream_t stream);

@@ -118,6 +118,31 @@ def _pq_dequant_impl(codes: torch.Tensor, codebooks: torch.Tensor, codebook_part
     return out
 
 
+def _pq_embedding_impl(input_ids: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor,
+                       scales: Optional[torch.Tensor], codebook_partition_sizes: List[int]) -> torch.Tensor:
+    L = _lib.load()
+    dev = _check_device(input_ids, codes, codebooks, scales)
+    N, G, M, K, d, parts = _format(codes, codebooks, codebook_partition_sizes)
+    if input_ids.dtype not in (torch.int64, torch.int32):
+        raise ValueError(f"input_ids dtype {input_ids.dtype}: int64 (or int32) indices expected")
+    if scales is not None:
+        if scales.numel() != N or scales.dtype != codebooks.dtype:
+            raise ValueError("scales must hold one value of the codebooks' dtype per output row")
+        scales = scales.contiguous()
+    ids = input_ids.reshape(-1).to(torch.int64).contiguous()
+    T = ids.numel()
+    out = torch.empty((T, G * d), dtype=codebooks.dtype, device=dev)
+    if T and G:
+        with torch.cuda.device(dev):
+            rc = L.pq_embedding(ids.data_ptr(), T, codes.contiguous().data_ptr(), codebooks.contiguous().data_ptr(),
+                                scales.data_ptr() if scales is not None else None, _lib.parts_array(parts), len(parts),
+                                N, G, M, K, d, _CODE_BYTES[codes.dtype], _DTYPE[codebooks.dtype], out.data_ptr(), G * d,
+                                _stream_ptr(dev))
+        if rc:
+            _raise(rc)
+    return out.reshape(tuple(input_ids.shape) + (G * d,))
+
+
 def _pq_gemm_impl(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor,
                   codebook_partition_sizes: List[int], bias: Optional[torch.Tensor],
                   packed_codes: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -190,6 +215,26 @@ if _HAVE_CUSTOM_OP:
     @_dequant_op.register_fake
     def _dequant_fake(codes, codebooks, codebook_partition_sizes, scales):
         return codebooks.new_empty((codes.shape[0], codes.shape[1] * codebooks.shape[3]))
+
+
+    @torch.library.custom_op("pq_amd::embedding", mutates_args=(), device_types="cuda")
+    def _embedding_op(input_ids: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor,
+                      scales: Optional[torch.Tensor], codebook_partition_sizes: List[int]) -> torch.Tensor:
+        return _pq_embedding_impl(input_ids, codes, codebooks, scales, codebook_partition_sizes)
+
+    @_embedding_op.register_fake
+    def _embedding_fake(input_ids, codes, codebooks, scales, codebook_partition_sizes):
+        return codebooks.new_empty(tuple(input_ids.shape) + (codes.shape[1] * codebooks.shape[3],))
+
+
+def pq_embedding(input_ids: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor,
+                 scales: Optional[torch.Tensor], codebook_partition_sizes: List[int]) -> torch.Tensor:
+    """Rows `input_ids` of the dequantised weight, [..., in_features]: F.embedding(input_ids, pq_dequant(...)) bit
+    for bit without building the table (UnquantizedEmbeddingMethod.embedding,
+    vllm/model_executor/layers/vocab_parallel_embedding.py:45-47, for a PQ-compressed table)."""
+    if _HAVE_CUSTOM_OP and input_ids.is_cuda:
+        return torch.ops.pq_amd.embedding(input_ids, codes, codebooks, scales, list(codebook_partition_sizes))
+    return _pq_embedding_impl(input_ids, codes, codebooks, scales, codebook_partition_sizes)
 
 
 def pq_gemm(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor,

@@ -11,6 +11,8 @@ vllm/model_executor/layers/quantization/aqlm.py:
     get_int_dtype       :20-29     unpack_int_data     :32-34
     PQConfig            <-> AQLMConfig :159-217
     PQLinearMethod      <-> AQLMLinearMethod :220-374 (create_weights :230-323, apply :325-374)
+    PQEmbeddingMethod   the same parameters on a vocabulary table: apply() for the LM head, embedding() for the
+                        input table (QuantizeMethodBase.embedding, base_config.py:30-35); opt-in, see PQConfig
 Differences, all on purpose: bf16 as well as fp16 activations; every (K, d, M) goes to the fused HIP
 kernels (the reference only accelerates d == 8 with (K, M) in {(256, 2), (65536, 1)} and falls back to
 PyTorch otherwise, aqlm.py:344-374); there is no CPU path here.  A format whose codebook does not fit LDS
@@ -24,8 +26,8 @@ import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from . import ops
-from .compat import (LinearBase, LinearMethodBase, QUANTIZATION_METHODS, QuantizationConfig,
-                     register_quantization_config, set_weight_attrs)
+from .compat import (LinearBase, LinearMethodBase, ParallelLMHead, QUANTIZATION_METHODS, QuantizationConfig,
+                     VocabParallelEmbedding, register_quantization_config, set_weight_attrs)
 
 PQ_METHOD_NAME = "pq"
 
@@ -50,8 +52,13 @@ class PQConfig(QuantizationConfig):
     out_group_size (must be 1)."""
 
     def __init__(self, in_group_size: int = 8, nbits_per_codebook: int = 8, num_codebooks: int = 1,
-                 out_group_size: int = 1) -> None:
+                 out_group_size: int = 1, lm_head: bool = False, embeddings: bool = False) -> None:
         super().__init__()
+        # The reference's codebook method quantises linear layers only (aqlm.py:213-217), and so does this one by
+        # default.  `lm_head` / `embeddings` (keys of the same names in the HF quantization_config) say that the
+        # checkpoint also holds codes/codebooks/scales for the output head / the input embedding table.
+        self.lm_head_quantized = bool(lm_head)
+        self.embeddings_quantized = bool(embeddings)
         self.in_group_size = int(in_group_size)
         self.nbits_per_codebook = int(nbits_per_codebook)
         self.num_codebooks = int(num_codebooks)
@@ -96,11 +103,16 @@ class PQConfig(QuantizationConfig):
             nbits = k.bit_length() - 1
         m = cls.get_from_keys_or(config, ["num_codebooks"], 1)
         og = cls.get_from_keys_or(config, ["out_group_size"], 1)
-        return cls(d, nbits, m, og)
+        return cls(d, nbits, m, og, lm_head=cls.get_from_keys_or(config, ["lm_head"], False),
+                   embeddings=cls.get_from_keys_or(config, ["embeddings"], False))
 
     def get_quant_method(self, layer: torch.nn.Module, prefix: str) -> Optional["PQLinearMethod"]:
         if isinstance(layer, LinearBase):
             return PQLinearMethod(self)
+        if isinstance(layer, ParallelLMHead):
+            return PQEmbeddingMethod(self) if self.lm_head_quantized else None
+        if isinstance(layer, VocabParallelEmbedding):
+            return PQEmbeddingMethod(self) if self.embeddings_quantized else None
         return None
 
 
@@ -209,6 +221,16 @@ class PQLinearMethod(LinearMethodBase):
             ops.silu_and_mul(out, y)
             return out
         return ops.pq_gemm_packed_silu_mul(x, packed, layer.codes, layer.codebooks, layer.scales, bias)
+
+
+class PQEmbeddingMethod(PQLinearMethod):
+    """PQ-compressed vocabulary table: [rows of this rank, embedding_dim] as one output partition.  apply() gives
+    the LM head's logits (the linear method's fused GEMM), embedding() the rows of the reconstructed table picked
+    by token ids -- bit for bit F.embedding over the dequantised table, which is never built."""
+
+    def embedding(self, layer: torch.nn.Module, input_: torch.Tensor) -> torch.Tensor:
+        parts = getattr(layer.codebooks, "output_partition_sizes", [])
+        return ops.pq_embedding(input_, layer.codes, layer.codebooks, layer.scales, parts)
 
 
 # batch size up to which a format without an MFMA kernel stays on the generic fused kernel (the reference switches
