@@ -135,6 +135,9 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
     constexpr bool PIPE = D == 8 && M == 1 && WN % 2 == 0 && WT % 2 == 0 && !(ABL & (8 | 16));
     // the same format on the shapes with a single weight fragment per wave: hand-issued reads, in batches of k-steps
     constexpr bool BATCH = D == 8 && M == 1 && !PIPE && !(ABL & (8 | 16));
+    // Blocks walk several tiles where the main loop is scheduled by hand; the compiler-scheduled formats keep one
+    // tile per block (measured: their main loop comes out 6-9 % slower inside the tile loop).
+    constexpr bool PERSIST = PIPE || BATCH;
     static_assert(KS % 2 == 0 && U % TPP == 0 && U % KT == 0, "pieces and stages must tile the loop step");
     static_assert(PPW >= 1, "tile too small for the block");
 
@@ -372,10 +375,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
         constexpr int AHEAD = DEEP ? 2 : 1;
         const int ureq = u + AHEAD < nsteps ? u + AHEAD : nsteps - 1;
         if constexpr (!PIPE) load_pieces(req, ureq);
-        static_for<SPU>([&](auto sgc) {
-            constexpr int sg = decltype(sgc)::value;
+        auto stage = [&](auto sgc) {     // sgc: the stage's number within the step, a compile-time constant for PIPE
+            const int sg = sgc;
             if constexpr (!PIPE) x_issue(u * SPU + sg + 2, buf2);
             if constexpr (PIPE) {
+                constexpr int sg = decltype(sgc)::value;
                 // The stage's global-memory requests -- in a step's first stage the code loads, then the activation
                 // DMA of stage st+2 -- go out one or two at a time behind the last MFMA of each group instead of in
                 // one burst at the head of the stage; codes first, so that they are older than the stage's DMA.
@@ -565,7 +569,13 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
             }
             buf = buf == NBUF - 1 ? 0 : buf + 1;
             buf2 = buf2 == NBUF - 1 ? 0 : buf2 + 1;
-        });
+        };
+        if constexpr (PIPE) {
+            static_for<SPU>(stage);
+        } else {
+#pragma unroll
+            for (int sg = 0; sg < SPU; ++sg) stage(sg);
+        }
     };
     constexpr std::integral_constant<bool, false> keep{};   // the request stays in flight into the next step
     constexpr std::integral_constant<bool, true> land{};    // nothing in flight when the step ends
@@ -591,13 +601,12 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
         }
         // Every step above ended with its code loads landed and with a barrier: no wave reads the ring or gathers
         // any more.  The activation DMA of the two stages past the end (re-reads of the last stage) may still be
-        // writing the ring slots `buf` and the one after it; the next tile's first two stages go to the same
-        // slots from the same waves, and a wave's DMA lands in issue order.
+        // writing the ring; a wave's DMA lands in issue order and writes that wave's pieces only.
         if (first) stamp(2);
 
         // ---- the block's next tile: its first two stages and its first codes travel during this tile's epilogue ----
         const int npin = pin + nslots;
-        const bool more = npin < per_xcd && run0 + npin < total;
+        const bool more = PERSIST && npin < per_xcd && run0 + npin < total;
         const TileSel done = cur_tile;
         if (more) cur_tile = tile_of(run0 + npin);   // otherwise the requests below re-read this tile: no branch around a load
         pin = npin;
@@ -620,20 +629,30 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
             sraw[i] = *reinterpret_cast<const u32x2 *>(scales + nc);
             braw[i] = (bias && !(ABL & 32)) ? *reinterpret_cast<const u32x2 *>(bias + nc) : u32x2{0u, 0u};
         }
+        if constexpr (PERSIST) {
         bind(cur_tile);
         load_pieces_tracked(c0, 0);
         load_pieces_tracked(c1, nsteps > 1 ? 1 : 0);
+        }
         // These loads are waited for here, before the DMA goes out: the compiler waits for a tracked load that is
         // pending beside an LDS-DMA with vmcnt(0), which would put the DMA's latency in front of the epilogue
         // arithmetic instead of behind it.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < WN; ++i) asm volatile("" : "+v"(sraw[i]), "+v"(braw[i]));
+        if constexpr (PERSIST) {
         landed(c0);
         landed(c1);
-        x_issue(0, buf);
-        x_issue(1, buf == NBUF - 1 ? 0 : buf + 1);
-        buf2 = buf >= NBUF - 2 ? buf + 2 - NBUF : buf + 2;
+        }
+        // The ring starts over at slot 0 for every tile, so that the slot of every stage of the unrolled main loop
+        // is a compile-time constant.  The DMA of the two stages past the end of the finished tile may still be
+        // writing the ring; it comes from the same waves as what is issued here and lands first.
+        if constexpr (PERSIST) {
+        buf = 0;
+        buf2 = 2;
+        x_issue(0, 0);
+        x_issue(1, 1);
+        }
 
         auto finish = [&](int i, int j, uint32_t &lo, uint32_t &hi) {   // fragment (i, j) -> two packed dwords
             uint16_t h[4];
@@ -741,7 +760,8 @@ static hipError_t tiled_launch_cfg(const GemmArgs &a, hipStream_t stream) {
         const char *env = getenv("PQ_AMD_TILED_SLOTS");   // tests and diagnosis: blocks per XCD (large: one tile per block)
         if (env && atoi(env) > 0) nslots = atoi(env);
     }
-    if (nslots > per_xcd) nslots = per_xcd;
+    constexpr bool persist = D == 8 && M == 1;     // the kernel's PERSIST
+    if (!persist || nslots > per_xcd) nslots = per_xcd;
     hipLaunchKernelGGL(kern, dim3(nslots * 8), dim3(TL_THREADS), lds, stream, static_cast<const uint16_t *>(a.x), a.T,
                        a.x_stride, static_cast<const u32x4 *>(a.codes), static_cast<const uint16_t *>(a.codebooks),
                        static_cast<const uint16_t *>(a.scales), static_cast<const uint16_t *>(a.bias),
