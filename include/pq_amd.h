@@ -135,7 +135,8 @@ int pq_gemm(const void *x, int32_t T, int64_t x_row_stride, const void *codes, c
  * pq_packed_codes_bytes: size of the packed buffer, or 0 when this format cannot be packed (a
  *   partition size that is not a multiple of 16, or a (d, K, M) the MFMA kernels do not take); the
  *   caller then keeps using pq_gemm on the reference layout.
- * pq_repack_codes: codes [N][G][M] -> packed (caller-allocated, 16-byte aligned, that many bytes).
+ * pq_repack_codes: codes [N][G][M] -> packed (caller-allocated, 16-byte aligned, that many bytes); the packed
+ *   buffer holds every code as its index (value mod K), which pq_gemm_packed relies on.
  * pq_gemm_packed: pq_gemm with `packed_codes` in place of `codes`; the same sums in the same order whenever
  *   both run the same kernel shape (the packed layout additionally unlocks the tiled kernel and the K split).
  */
