@@ -15,7 +15,7 @@ from vllm_pq_amd import ops  # noqa: E402
 
 SHAPES = {  # name: (partition sizes, Kin)
     "qkv": ([4096, 1024, 1024], 4096), "o": ([4096], 4096), "gate_up": ([14336, 14336], 4096),
-    "down": ([4096], 14336), "sq4k": ([4096], 4096), "sq8k": ([8192], 8192),
+    "down": ([4096], 14336), "lm_head": ([128256], 4096), "sq4k": ([4096], 4096), "sq8k": ([8192], 8192),
 }
 
 

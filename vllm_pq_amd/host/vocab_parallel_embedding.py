@@ -56,9 +56,14 @@ def pad_vocab_size(vocab_size: int, pad_to: int = DEFAULT_VOCAB_PADDING_SIZE) ->
     return -(-vocab_size // pad_to) * pad_to
 
 
+def _span(first: str, last: str) -> property:
+    return property(lambda self: getattr(self, last) - getattr(self, first))
+
+
 @dataclass
 class VocabParallelEmbeddingShardIndices:
-    """Token-id ranges of one rank: [padded_*) with the padding, [*) without."""
+    """Token-id ranges of one rank.  `padded_*`: the rank's slice of the padded base / added vocabulary; the plain
+    ones: the same slices cut at the real vocabulary sizes (what the rank actually holds)."""
     padded_org_vocab_start_index: int
     padded_org_vocab_end_index: int
     padded_added_vocab_start_index: int
@@ -68,45 +73,21 @@ class VocabParallelEmbeddingShardIndices:
     added_vocab_start_index: int
     added_vocab_end_index: int
 
-    @property
-    def num_org_elements(self) -> int:
-        return self.org_vocab_end_index - self.org_vocab_start_index
-
-    @property
-    def num_added_elements(self) -> int:
-        return self.added_vocab_end_index - self.added_vocab_start_index
-
-    @property
-    def num_org_elements_padded(self) -> int:
-        return self.padded_org_vocab_end_index - self.padded_org_vocab_start_index
-
-    @property
-    def num_added_elements_padded(self) -> int:
-        return self.padded_added_vocab_end_index - self.padded_added_vocab_start_index
-
-    @property
-    def num_org_vocab_padding(self) -> int:
-        return self.num_org_elements_padded - self.num_org_elements
-
-    @property
-    def num_added_vocab_padding(self) -> int:
-        return self.num_added_elements_padded - self.num_added_elements
-
-    @property
-    def num_elements_padded(self) -> int:
-        return self.num_org_elements_padded + self.num_added_elements_padded
+    # row counts, with and without the padding
+    num_org_elements = _span("org_vocab_start_index", "org_vocab_end_index")
+    num_added_elements = _span("added_vocab_start_index", "added_vocab_end_index")
+    num_org_elements_padded = _span("padded_org_vocab_start_index", "padded_org_vocab_end_index")
+    num_added_elements_padded = _span("padded_added_vocab_start_index", "padded_added_vocab_end_index")
+    num_org_vocab_padding = property(lambda self: self.num_org_elements_padded - self.num_org_elements)
+    num_added_vocab_padding = property(lambda self: self.num_added_elements_padded - self.num_added_elements)
+    num_elements_padded = property(lambda self: self.num_org_elements_padded + self.num_added_elements_padded)
 
     def __post_init__(self):
-        assert self.padded_org_vocab_start_index <= self.padded_org_vocab_end_index
-        assert self.padded_added_vocab_start_index <= self.padded_added_vocab_end_index
-        assert self.org_vocab_start_index <= self.org_vocab_end_index
-        assert self.added_vocab_start_index <= self.added_vocab_end_index
-        assert self.org_vocab_start_index <= self.padded_org_vocab_start_index
-        assert self.added_vocab_start_index <= self.padded_added_vocab_start_index
-        assert self.org_vocab_end_index <= self.padded_org_vocab_end_index
-        assert self.added_vocab_end_index <= self.padded_added_vocab_end_index
-        assert self.num_org_elements <= self.num_org_elements_padded
-        assert self.num_added_elements <= self.num_added_elements_padded
+        for kind in ("org", "added"):
+            lo, hi = getattr(self, f"{kind}_vocab_start_index"), getattr(self, f"{kind}_vocab_end_index")
+            plo, phi = getattr(self, f"padded_{kind}_vocab_start_index"), getattr(self, f"padded_{kind}_vocab_end_index")
+            if not (lo <= hi and plo <= phi and lo <= plo and hi <= phi and hi - lo <= phi - plo):
+                raise AssertionError(f"inconsistent {kind} vocabulary ranges: {self}")
 
 
 def get_masked_input_and_mask(input_: torch.Tensor, org_vocab_start_index: int, org_vocab_end_index: int,
