@@ -191,6 +191,24 @@ def test_gemm_one_hot_rows_reproduce_the_gather(ops):
     assert torch.equal(y, want)
 
 
+def test_misaligned_scales_and_bias_take_another_kernel(ops):
+    """The tiled kernel reads scales and bias eight bytes at a time and refuses tensors that are not 8-byte
+    aligned (views at an odd offset); the launch then runs on another kernel with the same result."""
+    parts, Kin, T = [512, 256], 1024, 200
+    p = Problem(18, 256, 8, 1, parts, Kin, T, "bf16", bias=True).to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    want = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    sc = torch.zeros(p.N + 1, 1, 1, 1, device=DEV, dtype=torch.bfloat16)
+    sc[1:] = p.scales_dev
+    bi = torch.zeros(p.N + 3, device=DEV, dtype=torch.bfloat16)
+    bi[3:] = p.bias_dev
+    assert sc[1:].data_ptr() % 8 and bi[3:].data_ptr() % 8
+    got = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, sc[1:], parts, bi[3:])
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(got), y32, "bf16", "misaligned scales/bias")
+    assert_close_to_exact(bits_of(want), y32, "bf16", "aligned scales/bias")
+
+
 @pytest.mark.parametrize("name,parts,Kin", [
     ("qkv_proj", [4096, 1024, 1024], 4096), ("o_proj", [4096], 4096),
     ("gate_up_proj", [14336, 14336], 4096), ("down_proj", [4096], 14336)])
