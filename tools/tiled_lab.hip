@@ -148,6 +148,8 @@ int main(int argc, char **argv) {
     if (argc > 3) g_slots = atoi(argv[3]);
     if (argc > 2 && argv[2][0] == 's') {
         stamps<2, 8, 4, 2>(T, 28672, 512, 2);
+        stamps<2, 8, 4, 2>(T, 4096, 512, 1);      // o_proj: one tile per block
+        stamps<2, 8, 4, 2>(T, 4096, 1792, 1);     // down_proj
         return 0;
     }
     if (argc > 2) {   // per-round constant against per-k slope: the same grid at growing Kin
