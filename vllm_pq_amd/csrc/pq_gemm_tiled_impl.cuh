@@ -66,21 +66,26 @@ __device__ __forceinline__ uint32_t gather_addr8(const VecT &w, int i, uint32_t 
     }
 }
 
-// The hand-pipelined stage issues its LDS reads in this order: activations of k-step 0, gathers of groups 0 and 1;
-// then group h (before and between its MFMAs): gathers of group h+2, activations of the next k-step when h is the
+// The hand-pipelined stage issues its LDS reads in this order: activations of k-step 0, gathers of groups 0 and 1
+// (PRE: the stage before it has issued them already, gathers first); then group h (before and between its MFMAs): gathers of group h+2, activations of the next k-step when h is the
 // first group of a k-step.  LDS reads return in order; this is the number of reads issued after the last one
 // group g's MFMAs need (its gathers and, for the first group of a k-step, that k-step's activations) and before
 // group g's wait: the n of its `s_waitcnt lgkmcnt(n)`.
-template <int NG, int NPAIR, int NKS, int WT>
+template <int NG, int NPAIR, int NKS, int WT, bool PRE = false>
 constexpr int pipe_newer(int g) {
     const int kk = g / NPAIR;
     const bool need_x = g % NPAIR == 0;
     int after = 0;          // reads issued after the last needed one so far
-    // prologue: X(0), G(0), G(1)
-    if (need_x && kk == 0) after = 0;
-    if (g == 0) after = 0;
-    else after += 2;        // G(0) is newer than X(0); not needed unless g == 0
-    if (NG > 1) { if (g == 1) after = 0; else after += 2; }
+    if (PRE) {
+        // issued by the stage before this one, in the gaps of its last group: G(0), G(1), X(0)
+        if (g == 0) after = 0; else after += 2;
+        if (NG > 1) { if (g == 1) after = 0; else after += 2; }
+        if (need_x && kk == 0) after = 0; else after += WT;
+    } else {
+        // prologue: X(0), G(0), G(1)
+        if (g == 0) after = 0; else after += 2;        // G(0) is newer than X(0)
+        if (NG > 1) { if (g == 1) after = 0; else after += 2; }
+    }
     for (int h = 0; h < g; ++h) {
         if (h + 2 < NG) { if (h + 2 == g) after = 0; else after += 2; }
         if (h % NPAIR == 0 && h / NPAIR + 1 < NKS) { if (need_x && h / NPAIR + 1 == kk) after = 0; else after += WT; }
@@ -370,8 +375,18 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
     int buf = 0, buf2 = 2;
     // `own` (DEEP only): the step also waits for its own request, so that no code load is in flight when it ends
     // -- used for the last step before a loop back edge or a branch.
-    auto step = [&](const piece_t (&cur)[PPU][WN], piece_t (&lands)[PPU][WN], piece_t (&req)[PPU][WN], int u, auto own_c) {
+    // Operand registers of the hand-pipelined stage.  With one stage per step they live across stages: a stage can
+    // request the first operands of the next one (mode bit 1), which then finds them issued (mode bit 0); the
+    // register set the gathers rotate through starts at `mode >> 2`.  Never across a branch or the loop's back edge.
+    u32x4 xfr[2][WT], P[3][2];
+    constexpr int NGK = KT * 2 * (WN / 2);           // groups per stage of the hand-pipelined path
+    constexpr bool XS = PIPE && SPU == 1 && CB == 1 && !(ABL & 1);   // two-byte codes: no registers to spare
+    auto step = [&](const piece_t (&cur)[PPU][WN], piece_t (&lands)[PPU][WN], piece_t (&req)[PPU][WN], int u, auto own_c,
+                    auto mode_c) {
         constexpr bool own = decltype(own_c)::value;
+        constexpr int mode = decltype(mode_c)::value;
+        constexpr bool PRE = XS && (mode & 1), NEXT = XS && (mode & 2);
+        constexpr int BASE = XS ? (mode >> 2) % 3 : 0;
         constexpr int AHEAD = DEEP ? 2 : 1;
         const int ureq = u + AHEAD < nsteps ? u + AHEAD : nsteps - 1;
         if constexpr (!PIPE) load_pieces(req, ureq);
@@ -395,7 +410,6 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                 // (two sets).  LDS reads return in order, so `lgkmcnt(n)` = all but the n newest.
                 constexpr int NKS = KT * 2, NPAIR = WN / 2, NG = NKS * NPAIR;
                 const uint32_t xs0 = xlane[0] + (uint32_t)buf * STAGE_BYTES, xs1 = xlane[1] + (uint32_t)buf * STAGE_BYTES;
-                u32x4 xfr[2][WT], P[3][2];
                 auto gather_pair = [&](auto gc, u32x4 (&dst)[2]) {        // group gc -> its two weight fragments
                     constexpr int g = decltype(gc)::value, kk = g / NPAIR, pp = g % NPAIR;
                     constexpr int tt_in = kk / 2, ks = kk % 2;
@@ -416,18 +430,37 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                 };
                 // reads group h issues before its MFMAs: the next k-step's activations (first group of a k-step)
                 auto xr = [](int h) constexpr { return (h >= 0 && h % NPAIR == 0 && h / NPAIR + 1 < NKS) ? WT : 0; };
-                read_x(std::integral_constant<int, 0>{});
-                gather_pair(std::integral_constant<int, 0>{}, P[0]);
-                if constexpr (NG > 1) gather_pair(std::integral_constant<int, (NG > 1 ? 1 : 0)>{}, P[1]);
+                static_assert(NG == NGK, "group count");
+                if constexpr (!PRE) {
+                    read_x(std::integral_constant<int, 0>{});
+                    gather_pair(std::integral_constant<int, 0>{}, P[BASE % 3]);
+                    if constexpr (NG > 1) gather_pair(std::integral_constant<int, (NG > 1 ? 1 : 0)>{}, P[(1 + BASE) % 3]);
+                }
                 static_for<NG>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value, kk = g / NPAIR, pp = g % NPAIR, c = g % 3, xb = kk & 1;
+                    constexpr int g = decltype(gc)::value, kk = g / NPAIR, pp = g % NPAIR, c = (g + BASE) % 3, xb = kk & 1;
                     constexpr bool G2 = g + 2 < NG, XR = xr(g) > 0;
                     constexpr int g2 = G2 ? g + 2 : g, kk2 = g2 / NPAIR, pp2 = g2 % NPAIR;
-                    constexpr int newer = pipe_newer<NG, NPAIR, NKS, WT>(g);
+                    constexpr int newer_all = pipe_newer<NG, NPAIR, NKS, WT, PRE>(g);
+                    constexpr int newer = newer_all > 15 ? 15 : newer_all;   // the counter has four bits; waiting for more is safe
+                    constexpr bool HANDOVER = NEXT && g == NG - 1;     // this group's gaps carry the next stage's first reads
                     asm volatile("s_waitcnt lgkmcnt(%2)\n\t; PQL %0\n\t; PQL %1" : "+v"(P[c][0]), "+v"(P[c][1]) : "n"(newer));
                     if constexpr (pp == 0) {
 #pragma unroll
                         for (int j = 0; j < WT; ++j) asm volatile("; PQL %0" : "+v"(xfr[xb][j]));
+                    }
+                    uint32_t na[4] = {0u, 0u, 0u, 0u};
+                    if constexpr (HANDOVER) {
+                        // Every LDS read of this stage has returned (the wait above was lgkmcnt(0)): the stage's end
+                        // -- next stage's DMA landed for this wave, then for all, and nobody reads this stage's slot
+                        // any more -- comes here, in front of the group's MFMAs, which then cover the barrier and
+                        // the latency of the next stage's first operands.
+                        static_assert(pipe_newer<NG, NPAIR, NKS, WT, PRE>(NG - 1) == 0, "last group waits for everything");
+                        if ((DEEP && !own) || SPU > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KT * PPW + CL) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KT * PPW) : "memory");
+                        landed(lands);
+                        if constexpr (DEEP && own) landed(req);
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
                     }
                     // the group's 2*WT MFMAs with its LDS traffic spread over the gaps between them, one or two
                     // instructions a gap: both gather addresses, the two gathers, then the next k-step's activations
@@ -443,14 +476,50 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                             for (int e2 = 0; e2 < 2; ++e2)
                                 ga[e2] = gather_addr8<CB>(cur[tt / TPP][2 * pp2 + e2], sidx, (uint32_t)nbits, shift, img_lane);
                         }
-                        if constexpr (G2 && (m == 1 || m == 2)) P[g2 % 3][m - 1] = lds_read16<0>(ga[m - 1]);
+                        if constexpr (G2 && (m == 1 || m == 2)) P[(g2 + BASE) % 3][m - 1] = lds_read16<0>(ga[m - 1]);
+                        if constexpr (HANDOVER) {
+                            // fillers of the hand-over: addresses, gathers of the next stage's groups 0 and 1 (from the
+                            // codes that have just landed), its first activation fragments (next ring slot)
+                            constexpr int NB_ = (BASE + NG) % 3;
+                            constexpr int last = 2 * WT - 1;
+                            auto filler = [&](auto ic) {
+                                constexpr int i = decltype(ic)::value;
+                                if constexpr (i == 0) {
+#pragma unroll
+                                    for (int h = 0; h < 2; ++h) {
+                                        const int kkh = h / NPAIR, pph = h % NPAIR;
+                                        const int tth = kkh / 2, sidxh = (tth % TPP) * 2 + kkh % 2;
+#pragma unroll
+                                        for (int e2 = 0; e2 < 2; ++e2)
+                                            na[2 * h + e2] = gather_addr8<CB>(lands[tth / TPP][2 * pph + e2], sidxh, (uint32_t)nbits, shift, img_lane);
+                                    }
+                                } else if constexpr (i <= 4) {
+                                    P[((i - 1) / 2 + NB_) % 3][(i - 1) % 2] = lds_read16<0>(na[i - 1]);
+                                } else {
+                                    constexpr int jx = i - 5;
+                                    const uint32_t nbuf = buf == NBUF - 1 ? 0u : (uint32_t)buf + 1u;
+                                    xfr[0][jx] = lds_read16<jx * 2048>(xlane[0] + nbuf * STAGE_BYTES);
+                                }
+                            };
+                            constexpr int NFILL = 5 + WT;
+                            if constexpr (m < last) {
+                                if constexpr (m < NFILL) filler(std::integral_constant<int, (m < NFILL ? m : 0)>{});
+                            } else {
+                                static_for<(NFILL > last ? NFILL - last : 0)>([&](auto dc) {
+                                    filler(std::integral_constant<int, last + decltype(dc)::value>{});
+                                });
+                            }
+                        }
                         if constexpr (XR && m >= 3 && m - 3 < WT) {
                             constexpr int jx = m - 3, kx = XR ? kk + 1 : kk;
                             constexpr int off = (kx / 2) * XT_BYTES + jx * 2048;
                             xfr[kx & 1][jx] = lds_read16<off>((kx % 2) ? xs1 : xs0);
                         }
-                        if constexpr (m == 2 * WT - 1) {
-                            constexpr int k0 = g * NOPS / NG, k1 = (g + 1) * NOPS / NG;
+                        if constexpr (m == 2 * WT - 1 && !HANDOVER) {
+                            // with a hand-over the stage's requests all go out before its last group (they are counted
+                            // by the wait in front of it)
+                            constexpr int NGV = NEXT ? NG - 1 : NG;
+                            constexpr int k0 = g * NOPS / NGV, k1 = (g + 1) * NOPS / NGV;
                             static_for<k1 - k0>([&](auto dc) { vm_op(std::integral_constant<int, k0 + decltype(dc)::value>{}); });
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -550,7 +619,9 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                 }
             }
             }
-            if constexpr (!(ABL & 1)) {
+            if constexpr (NEXT) {
+                // the stage's end was taken in front of its last group (hand-over)
+            } else if constexpr (!(ABL & 1)) {
                 // younger than the DMA of stage st+1: this stage's DMA and, in a step's first stage, its code loads
                 if (sg == 0 && ((DEEP && !own) || SPU > 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KT * PPW + CL) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KT * PPW) : "memory");
@@ -580,24 +651,31 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
     constexpr std::integral_constant<bool, false> keep{};   // the request stays in flight into the next step
     constexpr std::integral_constant<bool, true> land{};    // nothing in flight when the step ends
     for (int first = 1;; first = 0) {
+        // step modes: bit 0 = the step before has requested this one's first operands, bit 1 = this one requests the
+        // next one's, >> 2 = first gather register set.  Operands in flight only between steps with no branch between.
+        constexpr std::integral_constant<int, 0> alone{};
+        constexpr std::integral_constant<int, 2> opens{};
+        constexpr std::integral_constant<int, 1 | 2 | ((NGK % 3) << 2)> middle{};
+        constexpr std::integral_constant<int, 1 | (((2 * NGK) % 3) << 2)> last3{};
+        constexpr std::integral_constant<int, 1 | ((NGK % 3) << 2)> last2{};
         if constexpr (DEEP) {
             int u = 0;
             for (; u + 3 <= nsteps; u += 3) {
-                step(c0, c1, c2, u, keep);
-                step(c1, c2, c0, u + 1, keep);
-                step(c2, c0, c1, u + 2, land);
+                step(c0, c1, c2, u, keep, opens);
+                step(c1, c2, c0, u + 1, keep, middle);
+                step(c2, c0, c1, u + 2, land, last3);
             }
             if (u < nsteps) {
-                step(c0, c1, c2, u, land);
-                if (u + 1 < nsteps) step(c1, c2, c0, u + 1, land);
+                step(c0, c1, c2, u, land, alone);
+                if (u + 1 < nsteps) step(c1, c2, c0, u + 1, land, alone);
             }
         } else {
             int u = 0;
             for (; u + 2 <= nsteps; u += 2) {
-                step(c0, c1, c1, u, land);
-                step(c1, c0, c0, u + 1, land);
+                step(c0, c1, c1, u, land, opens);
+                step(c1, c0, c0, u + 1, land, last2);
             }
-            if (u < nsteps) step(c0, c1, c1, u, land);
+            if (u < nsteps) step(c0, c1, c1, u, land, alone);
         }
         // Every step above ended with its code loads landed and with a barrier: no wave reads the ring or gathers
         // any more.  The activation DMA of the two stages past the end (re-reads of the last stage) may still be
