@@ -46,8 +46,9 @@ void run(const char *label, int T, int N, int G, int nparts) {
     for (int b = 0; b < nblk; ++b) { t0 = std::min(t0, h[b * 8]); t1 = std::max(t1, h[b * 8 + 5]); }
     printf("%s NF=%d TF=%d T=%d N=%d Kin=%d blocks=%d: span first-start..last-end = %.2f us\n", label, NF, TF, T, N, G * D,
            nblk, (t1 - t0) / 100.0);
-    const char *names[] = {"start(since first)", "loads issued", "image built", "wave0 mfma done", "all waves done", "stores retired"};
-    for (int k = 0; k < 6; ++k) {
+    const char *names[] = {"start(since first)", "loads issued", "image built", "wave0 mfma done", "all waves done", "stores retired",
+                           "tile found", "codes+x requested"};
+    for (int k : {0, 6, 7, 1, 2, 3, 4, 5}) {
         std::vector<double> v;
         for (int b = 0; b < nblk; ++b) v.push_back((h[b * 8 + k] - t0) / 100.0);
         std::sort(v.begin(), v.end());

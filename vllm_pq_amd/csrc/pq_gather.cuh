@@ -42,34 +42,59 @@ __device__ inline uint32_t code_at(const VecT &w, int i, uint32_t nbits) {
 // The replicated codebook image of one partition in LDS: 16-byte slot j holds entry j / (EB*R/16).
 // Split in two so that the source loads (L2-resident, issued first) are in flight together with the
 // kernel's other global loads and the LDS stores wait for them alone.
+// When an entry fills at least MAX_IT slots (every format with a replicated image of full size), a thread reads ONE
+// entry and writes MAX_IT of its slots: one global load per thread instead of MAX_IT loads of the same bytes --
+// the texture path of a CU takes 16 cycles per 16-byte wave-load whatever the addresses, and a short kernel's
+// first microseconds are spent pushing its first loads through it.  The slots go out in a per-lane rotated order
+// so that the lanes of a store group land on different banks.
 template <int D, int THREADS>
 struct CodebookImage {
     static constexpr int EB = 2 * D;
     static constexpr int MAX_IT = (ST_MAX_LDS_CB / 16 + THREADS - 1) / THREADS;
     u32x4 v[MAX_IT];
 
+    static __device__ inline bool one_load(int R) { return ((EB * R) / 16) % MAX_IT == 0; }
+
+    __device__ inline u32x4 fetch(const unsigned char *cb_g, int e) const {
+        if constexpr (D == 8) {
+            return *reinterpret_cast<const u32x4 *>(cb_g + (size_t)e * 16);
+        } else if constexpr (D == 4) {
+            const u32x2 s2 = *reinterpret_cast<const u32x2 *>(cb_g + (size_t)e * 8);
+            return u32x4{s2.x, s2.y, s2.x, s2.y};
+        } else {
+            const uint32_t s1 = *reinterpret_cast<const uint32_t *>(cb_g + (size_t)e * 4);
+            return u32x4{s1, s1, s1, s1};
+        }
+    }
+
     __device__ inline void load(const unsigned char *cb_g, int entries, int R, int tid) {
         const int slots = (entries * EB * R) / 16;
-        const int per_entry_shift = __builtin_ctz((unsigned)((EB * R) / 16));
+        const int spe = (EB * R) / 16;                 // slots per entry
+        if (one_load(R)) {
+            const int e = tid / (spe / MAX_IT);
+            v[0] = fetch(cb_g, e < entries ? e : entries - 1);
+            return;
+        }
+        const int per_entry_shift = __builtin_ctz((unsigned)spe);
 #pragma unroll
         for (int it = 0; it < MAX_IT; ++it) {
             int j = tid + it * THREADS;
             j = j < slots ? j : slots - 1;     // clamp instead of branching; extra slots are not stored
-            const int e = j >> per_entry_shift;
-            if constexpr (D == 8) {
-                v[it] = *reinterpret_cast<const u32x4 *>(cb_g + (size_t)e * 16);
-            } else if constexpr (D == 4) {
-                const u32x2 s2 = *reinterpret_cast<const u32x2 *>(cb_g + (size_t)e * 8);
-                v[it].x = s2.x; v[it].y = s2.y; v[it].z = s2.x; v[it].w = s2.y;
-            } else {
-                const uint32_t s1 = *reinterpret_cast<const uint32_t *>(cb_g + (size_t)e * 4);
-                v[it].x = s1; v[it].y = s1; v[it].z = s1; v[it].w = s1;
-            }
+            v[it] = fetch(cb_g, j >> per_entry_shift);
         }
     }
     __device__ inline void store(unsigned char *smem, int entries, int R, int tid) const {
         const int slots = (entries * EB * R) / 16;
-        if (slots == MAX_IT * THREADS) {       // the common case (K*EB*R == 64 KiB): no predicates
+        if (one_load(R)) {
+            const int first = tid * MAX_IT;            // this thread's MAX_IT consecutive slots, all of one entry
+            if (first < slots) {
+#pragma unroll
+                for (int c = 0; c < MAX_IT; ++c)
+                    *reinterpret_cast<u32x4 *>(smem + (size_t)(first + ((c + tid) & (MAX_IT - 1))) * 16) = v[0];
+            }
+            return;
+        }
+        if (slots == MAX_IT * THREADS) {       // a full-size image: no predicates
 #pragma unroll
             for (int it = 0; it < MAX_IT; ++it)
                 *reinterpret_cast<u32x4 *>(smem + (size_t)(tid + it * THREADS) * 16) = v[it];

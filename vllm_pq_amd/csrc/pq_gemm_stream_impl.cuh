@@ -208,6 +208,7 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
 
     // ---- everything the first chunk needs is requested before anything is waited for: the codebook
     // entries (needed first), the wave's first codes (HBM, the long latency), its first activations (L2)
+    if constexpr (ABL & 64) if (tid == 0) stamps[6] = wall_clock64();   // tile found, addresses set up
     CodebookImage<D, ST_THREADS> img;
     CodebookImage<D, ACT ? ST_THREADS : 1 << 20> img_up;   // ACT: the up partition's codebook, a second full image
     if constexpr (!(ABL & 16))
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
         load_codes(cA, c_begin + wave);
         load_x(X[0], c_begin + wave, 0);
     }
+    if constexpr (ABL & 64) if (tid == 0) stamps[7] = wall_clock64();   // image source, codes, activations requested
     // ---- epilogue operands: this thread's output rows in each reduction round.  Fetched now, behind the
     // streaming loads and without touching the loaded registers, so that no global load sits on the tail.
     // round r, thread -> fragment fr = r*RF + tid/64 = (i, j) = (fr / TF, fr % TF); lane l of it holds
