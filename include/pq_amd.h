@@ -75,6 +75,14 @@ uint64_t pq_caps(void);
 const char *pq_last_error(void);
 
 /*
+ * Diagnostics only.  The dispatch knobs (environment variables PQ_AMD_FORCE_KERNEL, PQ_AMD_STREAM_CFG,
+ * PQ_AMD_STREAM_KSPLIT, PQ_AMD_TILED_CFG, PQ_AMD_TILED_SLOTS, PQ_AMD_DECODE_CFG) are read once, when the library is
+ * loaded, never per launch; tests and tuning tools that change them call this to have them read again.  Not to be
+ * called while another thread is inside the library.  No reference counterpart.
+ */
+void pq_debug_reload_knobs(void);
+
+/*
  * Reconstruct the dense weight  W[n][g*d + j] = sum_m codebooks[p(n)*M + m][idx(n,g,m)][j]
  * (x scales[n] when scales != NULL), out [N][G*d] in the act dtype.
  * M == 1 and scales == NULL is a pure gather and is bit-exact.  M > 1 sums in fp32 and rounds

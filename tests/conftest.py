@@ -44,3 +44,16 @@ def golden():
 @pytest.fixture(scope="session")
 def gold():
     return golden()
+
+
+@pytest.fixture(autouse=True)
+def _dispatch_knobs_restored():
+    """The library reads its PQ_AMD_* diagnostic knobs once; a test that sets them (monkeypatch.setenv followed by
+    _lib.reload_knobs()) leaves the library on the restored environment again."""
+    yield
+    try:
+        from vllm_pq_amd import _lib
+        if _lib._lib is not None:
+            _lib.reload_knobs()
+    except Exception:
+        pass

@@ -72,7 +72,7 @@ def test_packed_size_and_kernel_choice():
     assert L.pq_packed_codes_bytes(_lib.parts_array([64]), 1, 64, 64, 1, 65536, 8, 2) == 0      # K too large for LDS
     from vllm_pq_amd import ops
     name = ops.gemm_kernel_name
-    assert name(1, 6144, 512, 1, 256, 8, 1, torch.bfloat16, [4096, 1024, 1024], packed=True) == "mfma_stream_packed"
+    assert name(1, 6144, 512, 1, 256, 8, 1, torch.bfloat16, [4096, 1024, 1024], packed=True) == "mfma_decode_packed"
     assert name(4096, 6144, 512, 1, 256, 8, 1, torch.bfloat16, [4096, 1024, 1024], packed=True) == "mfma_tiled_packed"
     assert name(4, 64, 64, 1, 65536, 8, 2, torch.float16, [64]) == "generic"
     assert name(4, 60, 17, 1, 256, 8, 1, torch.float16, [60]) == "generic"

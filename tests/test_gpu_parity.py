@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from conftest import golden
+from vllm_pq_amd import _lib
 from oracle import pq_oracle as orc
 from pq_testlib import (Problem, assert_close_to_exact, assert_close_to_reference_order, bits_of, tensor_of)
 
@@ -81,6 +82,7 @@ def test_dequant_seeded(ops, K, d, M, parts, Kin, dtype):
 @pytest.mark.parametrize("case", G.cases("gemm"), ids=_id)
 def test_gemm_golden(ops, case, kernel, monkeypatch):
     monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "" if kernel == "auto" else kernel)
+    _lib.reload_knobs()
     dt = case["dtype"]
     codes, cb, sc = _golden_tensors(case)
     x = tensor_of(G.get(case, "x"), dt, DEV)
@@ -148,7 +150,7 @@ def test_gemm_packed_equals_reference_layout(ops, K, d, M, parts, Kin, T, dtype,
     assert packed is not None and packed.dtype == torch.uint8
     pname = ops.gemm_kernel_name(T, p.N, p.G, M, K, d, p.codes.element_size(), p.x.dtype, parts, packed=True)
     # the tiled kernel takes T > 16 when in_features is a whole number of its code pieces
-    assert pname in (("mfma_tiled_packed", "mfma_stream_packed") if T > 16 else ("mfma_stream_packed",))
+    assert pname in (("mfma_tiled_packed", "mfma_stream_packed") if T > 16 else ("mfma_stream_packed", "mfma_decode_packed"))
     y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
     _, y32 = p.oracle_gemm(order=2)
     assert_close_to_exact(bits_of(y), y32, dtype)
@@ -296,6 +298,7 @@ def test_tiled_kernel_every_tile_shape(ops, monkeypatch, cfg, dtype):
     packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
     monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "tiled")
     monkeypatch.setenv("PQ_AMD_TILED_CFG", str(cfg))
+    _lib.reload_knobs()
     y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
     y2 = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
     assert torch.equal(y, y2)                                   # run-to-run identical bits
@@ -318,8 +321,10 @@ def test_tiled_kernel_blocks_walk_several_tiles(ops, monkeypatch, slots, cfg, fm
     monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "tiled")
     monkeypatch.setenv("PQ_AMD_TILED_CFG", str(cfg))
     monkeypatch.setenv("PQ_AMD_TILED_SLOTS", "100000")
+    _lib.reload_knobs()
     y1 = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
     monkeypatch.setenv("PQ_AMD_TILED_SLOTS", str(slots))
+    _lib.reload_knobs()
     y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
     assert torch.equal(y, y1)
     _, y32 = p.oracle_gemm(order=2)
@@ -336,6 +341,7 @@ def test_tiled_kernel_other_formats_tile_shapes(ops, monkeypatch, fmt, cfg):
     assert packed is not None
     monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "tiled")
     monkeypatch.setenv("PQ_AMD_TILED_CFG", str(cfg))
+    _lib.reload_knobs()
     y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)
     _, y32 = p.oracle_gemm(order=2)
     assert_close_to_exact(bits_of(y), y32, "bf16", f"K={K} d={d} M={M} cfg {cfg}")
@@ -351,6 +357,7 @@ def test_stream_kernel_every_tile_shape(ops, monkeypatch, cfg, T):
     packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
     monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "stream")
     monkeypatch.setenv("PQ_AMD_STREAM_CFG", cfg)
+    _lib.reload_knobs()
     y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
     y2 = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
     assert torch.equal(y, y2)
@@ -406,6 +413,7 @@ def test_stream_kernel_k_split(ops, monkeypatch, T, ksplit):
     packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
     monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "stream")
     monkeypatch.setenv("PQ_AMD_STREAM_KSPLIT", str(ksplit))
+    _lib.reload_knobs()
     N, G = p.N, p.G
     need = ops.workspace_bytes(T, N, G, 1, 256, 8, 1, torch.bfloat16)
     assert need >= 16384 + ksplit * T * N * 4
@@ -457,6 +465,7 @@ def test_tiled_kernel_long_k_every_shape_and_format(ops, monkeypatch, fmt, cfg):
     assert packed is not None
     monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "tiled")
     monkeypatch.setenv("PQ_AMD_TILED_CFG", str(cfg))
+    _lib.reload_knobs()
     y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)
     _, y32 = p.oracle_gemm(order=2)
     assert_close_to_exact(bits_of(y), y32, "fp16" if cfg % 2 else "bf16", f"K={K} d={d} M={M} cfg {cfg}")

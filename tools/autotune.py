@@ -13,7 +13,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vllm_pq_amd import ops  # noqa: E402
+from vllm_pq_amd import _lib, ops  # noqa: E402
 from sweep import MODEL_SHAPES  # noqa: E402
 
 STREAM = ["1x1", "2x1", "4x1", "7x1", "8x1", "4x2", "7x2", "2x4", "4x4"]
@@ -25,6 +25,7 @@ def set_env(**kw):
         os.environ.pop(k, None)
     for k, v in kw.items():
         os.environ[k] = str(v)
+    _lib.reload_knobs()
 
 
 def time_call(fn, sets, reps=3):

@@ -17,7 +17,8 @@ PQ_DTYPE_FP16, PQ_DTYPE_BF16 = 0, 1
 # every symbol include/pq_amd.h declares
 EXPORTS = ("pq_version", "pq_caps", "pq_last_error", "pq_dequant", "pq_gemm_workspace_bytes", "pq_gemm",
            "pq_packed_codes_bytes", "pq_repack_codes", "pq_gemm_packed", "pq_gemm_kernel_name", "pq_silu_and_mul",
-           "pq_rms_norm", "pq_fused_add_rms_norm", "pq_gemm_silu_mul_is_fused", "pq_gemm_packed_silu_mul", "pq_embedding")
+           "pq_rms_norm", "pq_fused_add_rms_norm", "pq_gemm_silu_mul_is_fused", "pq_gemm_packed_silu_mul", "pq_embedding",
+           "pq_debug_reload_knobs")
 
 _lock = threading.Lock()
 _lib = None
@@ -83,10 +84,17 @@ def load():
         L.pq_gemm_packed_silu_mul.argtypes = [vp, i32, i64, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp,
                                               vp, sz, vp]
         L.pq_gemm_packed_silu_mul.restype = ctypes.c_int
+        L.pq_debug_reload_knobs.argtypes = []
+        L.pq_debug_reload_knobs.restype = None
         if L.pq_version() != PQ_ABI_VERSION:
             raise PQLibraryError(f"{LIB_PATH}: ABI version {L.pq_version()} != {PQ_ABI_VERSION}")
         _lib = L
     return _lib
+
+
+def reload_knobs() -> None:
+    """Diagnostics: have the library read the PQ_AMD_* dispatch knobs from the environment again."""
+    load().pq_debug_reload_knobs()
 
 
 def last_error() -> str:

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "pq_kernels.h"
+#include "pq_knobs.h"
 
 namespace {
 
@@ -55,15 +56,15 @@ int check_format(const char *fn, const int32_t *part_sizes, int num_parts, int N
     return PQ_OK;
 }
 
-enum Kernel { K_GENERIC = 0, K_STREAM = 1, K_TILED = 2 };
+enum Kernel { K_GENERIC = 0, K_STREAM = 1, K_TILED = 2, K_DECODE = 3 };
 
 Kernel choose(const pq::GemmArgs &a) {
-    const char *force = getenv("PQ_AMD_FORCE_KERNEL");  // "generic" | "stream" | "tiled": tests and profiling
-    if (force && *force) {
-        if (!strcmp(force, "generic")) return K_GENERIC;
-        if (!strcmp(force, "stream") && pq::gemm_stream_supported(a)) return K_STREAM;
-        if (!strcmp(force, "tiled") && pq::gemm_tiled_supported(a)) return K_TILED;
-    }
+    const int force = pq::knobs().force_kernel;
+    if (force == K_GENERIC) return K_GENERIC;
+    if (force == K_STREAM && pq::gemm_stream_supported(a)) return K_STREAM;
+    if (force == K_TILED && pq::gemm_tiled_supported(a)) return K_TILED;
+    if (force == K_DECODE && pq::gemm_decode_supported(a)) return K_DECODE;
+    if (force < 0 && pq::gemm_decode_supported(a)) return K_DECODE;
     const bool st = pq::gemm_stream_supported(a);
     const bool ti = pq::gemm_tiled_supported(a);
     if (ti && st && a.T > 16) {
@@ -92,7 +93,38 @@ Kernel choose(const pq::GemmArgs &a) {
 
 }  // namespace
 
+namespace pq {
+
+static Knobs read_knobs() {
+    Knobs k{-1, 0, 0, 0, -1, 0, 0, 0};
+    const char *e = getenv("PQ_AMD_FORCE_KERNEL");
+    if (e && *e) {
+        if (!strcmp(e, "generic")) k.force_kernel = K_GENERIC;
+        else if (!strcmp(e, "stream")) k.force_kernel = K_STREAM;
+        else if (!strcmp(e, "tiled")) k.force_kernel = K_TILED;
+        else if (!strcmp(e, "decode")) k.force_kernel = K_DECODE;
+    }
+    e = getenv("PQ_AMD_STREAM_CFG");
+    if (e && *e && sscanf(e, "%dx%d", &k.stream_nf, &k.stream_tf) != 2) k.stream_nf = k.stream_tf = 0;
+    e = getenv("PQ_AMD_STREAM_KSPLIT");
+    if (e && *e) k.stream_ksplit = atoi(e);
+    e = getenv("PQ_AMD_TILED_CFG");
+    if (e && *e) k.tiled_cfg = atoi(e);
+    e = getenv("PQ_AMD_TILED_SLOTS");
+    if (e && *e) k.tiled_slots = atoi(e);
+    e = getenv("PQ_AMD_DECODE_CFG");
+    if (e && *e && sscanf(e, "%dx%d", &k.decode_waves, &k.decode_nf) != 2) k.decode_waves = k.decode_nf = 0;
+    return k;
+}
+static Knobs g_knobs = read_knobs();   // at library load
+const Knobs &knobs() { return g_knobs; }
+void reload_knobs() { g_knobs = read_knobs(); }
+
+}  // namespace pq
+
 extern "C" {
+
+void pq_debug_reload_knobs(void) { pq::reload_knobs(); }
 
 int pq_version(void) { return PQ_ABI_VERSION; }
 
@@ -185,6 +217,7 @@ static int run_gemm(const char *fn, bool packed, const void *x, int32_t T, int64
     switch (k) {
     case K_TILED: e = pq::launch_gemm_tiled(a, s); break;
     case K_STREAM: e = pq::launch_gemm_stream(a, s); break;
+    case K_DECODE: e = pq::launch_gemm_decode(a, s); break;
     default: e = pq::launch_gemm_generic(a, s); break;
     }
     if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "%s: %s", fn, hipGetErrorString(e));
@@ -245,7 +278,7 @@ int pq_gemm_kernel_name(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, i
     a.packed = packed != 0;
     if (a.packed && !pq::packable(a.parts, d, K, M, code_bytes))
         return fail(PQ_ERR_UNSUPPORTED, "pq_gemm_kernel_name: this format has no packed layout");
-    static const char *names[] = {"generic", "mfma_stream", "mfma_tiled"};
+    static const char *names[] = {"generic", "mfma_stream", "mfma_tiled", "mfma_decode"};
     snprintf(buf, buf_len, "%s%s", names[choose(a)], a.packed ? "_packed" : "");
     return PQ_OK;
 }

@@ -1,0 +1,102 @@
+// Host side of the decode kernel (pq_gemm_decode_impl.cuh): which problems it takes, its launch geometry.
+#include <atomic>
+
+#include "pq_gemm_decode_impl.cuh"
+#include "pq_knobs.h"
+
+namespace pq {
+
+bool gemm_decode_supported(const GemmArgs &a) {
+    if (!a.packed || a.d != 8 || a.M != 1 || a.code_bytes != 1) return false;
+    if (a.K < 16 || a.K > 256 || (a.K & (a.K - 1))) return false;
+    if (a.T < 1 || a.T > 16 || a.G < 64 || a.G % 64) return false;          // whole 512-feature chunks
+    if (a.x_stride % 8 || (uint64_t)a.x_stride * 2 * 16 >= (1ull << 31)) return false;
+    if (a.N <= 0 || (int64_t)a.N * 2 >= (1ll << 31)) return false;
+    if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.codes) | reinterpret_cast<uintptr_t>(a.codebooks)) & 15)
+        return false;
+    if ((reinterpret_cast<uintptr_t>(a.scales) | reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.y)) & 7) return false;
+    if (a.y_stride % 4) return false;
+    for (int p = 0; p < a.parts.num; ++p)
+        if (a.parts.size[p] % 16) return false;
+    return a.G / 64 <= DC_UMAX * DC_MAX_WAVES;   // every wave's chunks fit its staging slots
+}
+
+// Waves along K: as many as there are chunks, up to 8 (a power of two; three chunks take four waves).  Then the
+// block shape with the shortest modelled launch: rounds of one block per CU, each a fixed cost plus its units in
+// sequence.  nf <= WK (one output fragment per wave in the epilogue) and nf * chunks per wave <= DC_UMAX.
+DecodeGeom choose_decode_geom(const GemmArgs &a) {
+    const int nchunks = a.G / 64;
+    DecodeGeom g;
+    g.wk_log2 = nchunks >= 5 ? 3 : nchunks >= 3 ? 2 : nchunks >= 2 ? 1 : 0;
+    const int WK = 1 << g.wk_log2;
+    g.c = (nchunks + WK - 1) / WK;
+    if (g.c > DC_UMAX) { g.nf = 0; g.waves = 0; return g; }   // K too long for the staging area: not taken
+    double best = -1.0;
+    g.nf = 1;
+    g.waves = WK;
+    if (knobs().decode_waves) {   // PQ_AMD_DECODE_CFG = "WAVESxNF", for tuning
+        const int w = knobs().decode_waves, nf = knobs().decode_nf;
+        if (w % WK == 0 && w >= WK && w <= DC_MAX_WAVES && !((w / WK) & (w / WK - 1)) && nf >= 1 && nf <= WK && nf * g.c <= DC_UMAX) {
+            g.nf = nf;
+            g.waves = w;
+            return g;
+        }
+    }
+    for (int wr = 1; wr * WK <= DC_MAX_WAVES; wr *= 2) {
+        for (int nf = 1; nf <= WK && nf * g.c <= DC_UMAX; ++nf) {
+            const long tiles = tiles_in(a.parts, wr * nf * 16);
+            const double rounds = (double)((tiles + 255) / 256);
+            // fixed: launch ramp, image, epilogue; per unit of a wave about 0.3 us; blocks of few waves share a CU
+            const double cost = rounds * (3.0 + 0.3 * nf * g.c) + (tiles < 256 ? 0.002 * (256 - tiles) : 0.0) * nf * g.c;
+            if (best < 0.0 || cost < best) { best = cost; g.nf = nf; g.waves = wr * WK; }
+        }
+    }
+    return g;
+}
+
+template <typename AT>
+static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipStream_t stream) {
+    DecodeParams p;
+    p.x = static_cast<const unsigned char *>(a.x);
+    p.codes = static_cast<const unsigned char *>(a.codes);
+    p.codebooks = static_cast<const unsigned char *>(a.codebooks);
+    p.scales = static_cast<const uint16_t *>(a.scales);
+    p.bias = static_cast<const uint16_t *>(a.bias);
+    p.y = static_cast<uint16_t *>(a.y);
+    p.y_stride = a.y_stride;
+    p.x_stride_bytes = (uint32_t)(a.x_stride * 2);
+    p.T = a.T;
+    p.nchunks = a.G / 64;
+    p.K = a.K;
+    p.nf = g.nf;
+    p.wk_log2 = g.wk_log2;
+    p.img_bytes = (uint32_t)a.K * 256u;
+    const int rows = (g.waves >> g.wk_log2) * g.nf * 16;
+    p.tmap = make_tile_map(a.parts, rows);
+    const dim3 grid(tiles_in(a.parts, rows));
+    const size_t lds = (size_t)p.img_bytes + (size_t)g.waves * DC_UMAX * 1024;
+    auto launch = [&](auto kern) -> hipError_t {
+        static std::atomic<bool> attr_set[64];   // per device: more than the default 64 KiB of LDS
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!attr_set[dev].load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               65536 + DC_STAGE_BYTES);
+            if (e != hipSuccess) return e;
+            attr_set[dev].store(true, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(g.waves * 64), lds, stream, p);
+        return hipGetLastError();
+    };
+    if (g.c > 1) return launch(gemm_decode_kernel<AT, true>);
+    return launch(gemm_decode_kernel<AT, false>);
+}
+
+hipError_t launch_gemm_decode(const GemmArgs &a, hipStream_t stream) {
+    if (a.N == 0 || a.T == 0) return hipSuccess;
+    const DecodeGeom g = choose_decode_geom(a);
+    if (g.nf == 0) return hipErrorInvalidValue;
+    return a.dtype == PQ_DTYPE_BF16 ? launch_decode_at<bf16_t>(a, g, stream) : launch_decode_at<fp16_t>(a, g, stream);
+}
+
+}  // namespace pq

@@ -1,0 +1,388 @@
+// Fused codebook gather + MFMA GEMM for decode batches (at most 16 tokens) on gfx950: d = 8, one codebook of at
+// most 256 entries, one-byte codes in the PACKED order (pq_gemm_stream.hip).
+//
+// y[t][n] = scale[n] * sum_k x[t][k] * W[n][k] + bias[n],   W[n][8g..8g+7] = centroid(code[n][g])
+//
+// Same arithmetic as the streaming kernel (pq_gemm_stream_impl.cuh): the weight fragment of
+// v_mfma_f32_16x16x32 is read straight out of the replicated LDS codebook image at the address the lane's code
+// byte selects, the activations are the B operand and stay in registers, K is split over the waves of a block
+// and the partial sums meet in LDS in a fixed order.  What differs is how the launch is built, because a decode
+// launch lasts a few microseconds and two things set its length that do not matter in a long kernel:
+//
+//  * Instruction fetch.  Every launch starts with a cold instruction cache, and straight-line code that is
+//    executed once runs at the rate the cache fills (measured: 12.5 cycles per 8-byte instruction cold against
+//    5 warm with 8 waves per CU), so 1 KiB of code that is executed once costs about 0.7 us.  This kernel is
+//    a few short loops: a unit (one 16-row fragment x one 512-feature chunk: 16 gathers + 16 MFMAs) is ONE loop
+//    body, whatever the tile shape; tile shape, waves per block and K split are run-time values.
+//  * Requests first.  The codes never pass through registers: every wave sends all its units' code pieces
+//    (1 KiB each) from HBM straight into an LDS staging area by LDS-DMA before it computes anything, so the
+//    whole HBM stream of the launch is requested in its first microsecond; a unit is computed when its piece has
+//    landed (loads return in order; the wait is a counted vmcnt).  A unit's accumulator lives in the staging
+//    slot its codes came in, so the loop body does not depend on the fragment either.
+//
+// Work split: a block of WK x WR waves owns WR * nf fragments (16 rows each) of one output partition and all of
+// K; wave (wk, wr) takes chunks wk, wk + WK, ... of fragments wr * nf .. + nf - 1.  The activations of a chunk
+// (16 x 16 bytes per lane) are loaded once per chunk and reused by the nf fragments.
+#pragma once
+#include "pq_common.cuh"
+#include "pq_kernels.h"
+
+namespace pq {
+
+constexpr int DC_MAX_WAVES = 8;
+constexpr int DC_UMAX = 8;                       // units of a wave (chunks x fragments): 1 KiB of staging each
+constexpr int DC_STAGE_BYTES = DC_MAX_WAVES * DC_UMAX * 1024;
+
+struct DecodeParams {
+    const unsigned char *x;        // [T][x_stride] act dtype
+    const unsigned char *codes;    // packed pieces
+    const unsigned char *codebooks;
+    const uint16_t *scales;
+    const uint16_t *bias;          // nullable
+    uint16_t *y;
+    int64_t y_stride;              // elements
+    uint32_t x_stride_bytes;
+    int T;
+    int nchunks;                   // 512-feature chunks of K
+    int K;                         // codebook entries (power of two, 16 .. 256)
+    int nf;                        // fragments per wave
+    int wk_log2;                   // log2 of the waves along K
+    uint32_t img_bytes;            // K * 256, the staging area follows
+    TileMap tmap;                  // tiles of (blockDim/64 >> wk_log2) * nf * 16 rows
+};
+
+// ---- hand-issued memory instructions -------------------------------------------------------------------------
+// The compiler tracks none of these; every wait is counted by hand.  "; PQX" marks a global load whose register
+// stays in flight across branches (checked over the whole kernel: nothing but such loads and MFMAs may touch
+// it), "; PQI" / "; PQL" an LDS read and the point from which its register may be read (no branch in between).
+template <int OFF>
+__device__ __forceinline__ u32x4 dc_gload16(uint32_t voff, const unsigned char *sbase) {
+    u32x4 v;
+    asm volatile("; PQX %0\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ u32x2 dc_gload8(uint32_t voff, const void *sbase) {
+    u32x2 v;
+    asm volatile("; PQX %0\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+    return v;
+}
+// 1 KiB from global memory straight into LDS at `lds_addr` (wave-uniform) + lane * 16
+__device__ __forceinline__ void dc_dma16(uint32_t lds_addr, uint32_t voff, const unsigned char *sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+__device__ __forceinline__ u32x4 dc_lds_read16(uint32_t addr) {
+    u32x4 v;
+    asm volatile("; PQI %0\n\tds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+template <typename V>
+__device__ __forceinline__ void dc_landed(V &v) { asm volatile("; PQL %0" : "+v"(v)); }
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate; n above 47 waits for 47):
+// a computed jump into a table of 48 {s_waitcnt vmcnt(k); s_branch end} pairs of 8 bytes each.  s_getpc_b64 returns
+// the address of the instruction behind it, 12 bytes in front of the table.
+#define DC_VM_ENTRY(k) "s_waitcnt vmcnt(" #k ")\n\ts_branch 9f\n\t"
+__device__ __forceinline__ void dc_wait_vm(int n) {
+    asm volatile(
+        "s_min_u32 s98, %0, 47\n\t"
+        "s_lshl_b32 s98, s98, 3\n\t"
+        "s_add_u32 s98, s98, 12\n\t"
+        "s_getpc_b64 s[96:97]\n\t"
+        "s_add_u32 s96, s96, s98\n\t"
+        "s_addc_u32 s97, s97, 0\n\t"
+        "s_setpc_b64 s[96:97]\n\t"
+        DC_VM_ENTRY(0) DC_VM_ENTRY(1) DC_VM_ENTRY(2) DC_VM_ENTRY(3) DC_VM_ENTRY(4) DC_VM_ENTRY(5) DC_VM_ENTRY(6) DC_VM_ENTRY(7)
+        DC_VM_ENTRY(8) DC_VM_ENTRY(9) DC_VM_ENTRY(10) DC_VM_ENTRY(11) DC_VM_ENTRY(12) DC_VM_ENTRY(13) DC_VM_ENTRY(14) DC_VM_ENTRY(15)
+        DC_VM_ENTRY(16) DC_VM_ENTRY(17) DC_VM_ENTRY(18) DC_VM_ENTRY(19) DC_VM_ENTRY(20) DC_VM_ENTRY(21) DC_VM_ENTRY(22) DC_VM_ENTRY(23)
+        DC_VM_ENTRY(24) DC_VM_ENTRY(25) DC_VM_ENTRY(26) DC_VM_ENTRY(27) DC_VM_ENTRY(28) DC_VM_ENTRY(29) DC_VM_ENTRY(30) DC_VM_ENTRY(31)
+        DC_VM_ENTRY(32) DC_VM_ENTRY(33) DC_VM_ENTRY(34) DC_VM_ENTRY(35) DC_VM_ENTRY(36) DC_VM_ENTRY(37) DC_VM_ENTRY(38) DC_VM_ENTRY(39)
+        DC_VM_ENTRY(40) DC_VM_ENTRY(41) DC_VM_ENTRY(42) DC_VM_ENTRY(43) DC_VM_ENTRY(44) DC_VM_ENTRY(45) DC_VM_ENTRY(46) DC_VM_ENTRY(47)
+        "9:"
+        ::"s"(n) : "memory", "s96", "s97", "s98", "scc");
+}
+#undef DC_VM_ENTRY
+
+// d = lanes in `mask` ? b : (a rotated by 8 lanes within every row of 16): one v_cndmask_b32_dpp per dword
+__device__ __forceinline__ u32x4 dc_sel_ror8(const u32x4 &a, const u32x4 &b, uint64_t mask) {
+    u32x4 d;
+    asm("s_mov_b64 vcc, %12\n\t"
+        "v_cndmask_b32_dpp %0, %4, %8, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %1, %5, %9, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %2, %6, %10, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %3, %7, %11, vcc row_ror:8 row_mask:0xf bank_mask:0xf"
+        : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w)
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "s"(mask)
+        : "vcc");
+    return d;
+}
+
+struct DcX { u32x4 f[16]; };   // the activations of one chunk: k-step s of lane (t, q) = x[t][chunk * 512 + 32 s + 8 q .. + 7]
+
+// MULTI: a wave may own more than one chunk (a second activation register set, loaded one chunk ahead)
+// STAMPS (diagnostic builds only): thread 0 writes wall-clock stamps of the phases to `bias` (8 x u64 per block)
+template <typename AT, bool MULTI, bool STAMPS = false>
+__global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const DecodeParams p) {
+    typedef typename Act<AT>::vec8 vec8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint16_t *bias = p.bias;
+    // STAMPS: the first and the last wave keep 12 wall-clock stamps each in registers and store them at the very end
+    // (24 x u64 per block behind `bias`): a store in between would sit in the memory pipeline with the loads
+    unsigned long long st[12];
+    if constexpr (STAMPS) {
+        bias = nullptr;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) st[k] = 0;
+        st[0] = __builtin_amdgcn_s_memrealtime();
+    }
+#define DC_STAMP(k) if constexpr (STAMPS) { asm volatile("" ::: "memory"); st[k] = __builtin_amdgcn_s_memrealtime(); asm volatile("" ::: "memory"); }
+    const int WK = 1 << p.wk_log2;
+    const int wk = wave & (WK - 1), wr = wave >> p.wk_log2;
+    const int nf = p.nf;
+    const int frags_blk = (int)((blockDim.x >> 6) >> p.wk_log2) * nf;
+    const TileLoc loc = locate_tile(p.tmap, (int)blockIdx.x, frags_blk * 16);
+    const int nfr = loc.nrows >> 4;                       // valid fragments of the tile (partitions are multiples of 16 rows)
+    const int f0 = loc.row0 >> 4;
+    const int nck = (p.nchunks - wk + WK - 1) >> p.wk_log2;   // chunks of this wave: wk, wk + WK, ...
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const uint32_t stage0 = lds0 + p.img_bytes + (uint32_t)wave * (DC_UMAX * 1024);   // this wave's staging slots
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+
+    // ---- requests.  The memory pipeline of a CU returns data in request order across ALL its waves, and the
+    // activation loads (16 rows x 64 bytes per wave-instruction) are what it spends most of its time on: 128 KiB
+    // at 16 tokens and K = 4096, 2.2 us.  So the code pieces (HBM) are requested in between them, one behind every
+    // second activation load: their latency and the HBM stream then run while the pipeline works through the
+    // activations, and everything has landed shortly after the last activation load has.
+    // Sequence numbers (codebook entries not counted): activation load s of the first chunk sits at
+    // s + min(U, s / 2), code piece j at 3 j + 2; then the second chunk's activations (MULTI), scales, bias.
+    const int U = nck * nf;                           // this wave's units (at most DC_UMAX)
+    DC_STAMP(1)   // tile found
+    int issued = 0;
+    // codebook image: entry e fills 16 slots of 16 bytes (one per lane residue); a thread owns spt consecutive slots
+    const int nthreads = (int)blockDim.x;
+    const int slots = p.K << 4;
+    const int spt = slots >= nthreads ? slots / nthreads : 1;
+    const bool img_active = tid * spt < slots;
+    const int ncb = spt > 16 ? spt >> 4 : 1;          // entries per thread (blocks of one or two waves: up to 4)
+    const int spe = spt > 16 ? 16 : spt;              // slots of one entry that this thread writes
+    const int e0 = img_active ? (tid * spt) >> 4 : 0;
+    const unsigned char *cb_part = p.codebooks + (size_t)loc.part * p.K * 16;
+    u32x4 cbv0 = dc_gload16<0>((uint32_t)e0 * 16u, cb_part), cbv1{0u, 0u, 0u, 0u}, cbv2{0u, 0u, 0u, 0u}, cbv3{0u, 0u, 0u, 0u};
+    if (ncb > 1) {
+        cbv1 = dc_gload16<16>((uint32_t)e0 * 16u, cb_part);
+        if (ncb > 2) {
+            cbv2 = dc_gload16<32>((uint32_t)e0 * 16u, cb_part);
+            cbv3 = dc_gload16<48>((uint32_t)e0 * 16u, cb_part);
+        }
+    }
+    // Activations.  MFMA k-step s wants lane (q = l >> 4, c = l & 15) to hold x[token c][32 s + 8 q .. + 7]: 16 rows x 64
+    // bytes per wave-load, which the memory pipeline serves four times slower than whole 128-byte lines.  So a
+    // pair of loads fetches one line (two k-steps) of tokens 0..7 and of tokens 8..15: lane (q, c) takes piece
+    // q + 4 (c >> 3) of token (c & 7) [+ 8]; the two k-steps' operands are then one row-local select each
+    // (dc_sel_ror8): k-step 2m = lanes c < 8 of the first load | lanes c - 8 of the second, k-step 2m + 1 the rest.
+    const int xc = lane & 7;
+    const uint32_t xpiece = (uint32_t)((lane >> 4) + 4 * ((lane >> 3) & 1)) * 16u;
+    const uint32_t xoff_a = (uint32_t)(xc < p.T ? xc : p.T - 1) * p.x_stride_bytes + xpiece;
+    const uint32_t xoff_b = (uint32_t)(xc + 8 < p.T ? xc + 8 : p.T - 1) * p.x_stride_bytes + xpiece;
+    const uint64_t lo_lanes = 0x00ff00ff00ff00ffull, hi_lanes = 0xff00ff00ff00ff00ull;
+    // unit j = cc * nf + i is chunk wk + cc * WK of fragment wr * nf + i (clamped to the tile); its piece goes to slot j
+    int dma_j = 0, dma_i = 0;
+    const size_t frag_bytes = (size_t)p.nchunks * 1024;
+    const unsigned char *dma_chunk = p.codes + (size_t)wk * 1024;
+    auto issue_dma = [&]() {
+        if (dma_j < U) {
+            const int fi = wr * nf + dma_i;
+            dc_dma16(stage0 + (uint32_t)dma_j * 1024u, lane16, dma_chunk + (size_t)(f0 + (fi < nfr ? fi : nfr - 1)) * frag_bytes);
+            ++dma_j;
+            ++issued;
+            if (++dma_i == nf) {
+                dma_i = 0;
+                dma_chunk += (size_t)WK * 1024;
+            }
+        }
+    };
+    auto put_image = [&]() {
+        if (img_active) {
+            auto put = [&](const u32x4 &v, int base) {
+#pragma nounroll
+                for (int c = 0; c < spe; ++c)    // rotated per thread so that a store group's lanes land on different banks
+                    *reinterpret_cast<u32x4 *>(smem + (size_t)(base + ((c + tid) & (spe - 1))) * 16) = v;
+            };
+            const int first = tid * spt;
+            put(cbv0, first);
+            if (ncb > 1) {
+                put(cbv1, first + 16);
+                if (ncb > 2) {
+                    put(cbv2, first + 32);
+                    put(cbv3, first + 48);
+                }
+            }
+        }
+    };
+    DcX XA, XB;
+    const unsigned char *xb0 = p.x + (size_t)(wk < p.nchunks ? wk : p.nchunks - 1) * 1024;
+#define DC_XL(s) XA.f[s] = dc_gload16<128 * ((s) >> 1)>((s) & 1 ? xoff_b : xoff_a, xb0); ++issued;
+    DC_XL(0) DC_XL(1) issue_dma();
+    DC_XL(2) DC_XL(3) issue_dma();
+    DC_XL(4) DC_XL(5) issue_dma();
+    DC_XL(6) DC_XL(7) issue_dma();
+    // the codebook entries are older than everything counted in `issued`: they have landed when no more than that is
+    // outstanding; the image is stored while the pipeline works through the requests made so far
+    DC_STAMP(2)   // first half requested
+    dc_wait_vm(issued);
+    DC_STAMP(3)   // codebook entries landed
+    dc_landed(cbv0); dc_landed(cbv1); dc_landed(cbv2); dc_landed(cbv3);
+    put_image();
+    DC_STAMP(4)   // image stored
+    DC_XL(8) DC_XL(9) issue_dma();
+    DC_XL(10) DC_XL(11) issue_dma();
+    DC_XL(12) DC_XL(13) issue_dma();
+    DC_XL(14) DC_XL(15) issue_dma();
+#undef DC_XL
+    int seq_xa = 15 + (U < 7 ? U : 7), seq_xb = 0;    // sequence number of the set's last load
+    auto issue_x = [&](DcX &X, int chunk) {
+        const unsigned char *xb = p.x + (size_t)(chunk < p.nchunks ? chunk : p.nchunks - 1) * 1024;
+#define DC_XL(s) X.f[s] = dc_gload16<128 * ((s) >> 1)>((s) & 1 ? xoff_b : xoff_a, xb);
+        DC_XL(0) DC_XL(1) DC_XL(2) DC_XL(3) DC_XL(4) DC_XL(5) DC_XL(6) DC_XL(7)
+        DC_XL(8) DC_XL(9) DC_XL(10) DC_XL(11) DC_XL(12) DC_XL(13) DC_XL(14) DC_XL(15)
+#undef DC_XL
+        issued += 16;
+    };
+    DC_STAMP(5)   // first chunk's activations and the codes requested
+    if constexpr (MULTI) {
+        issue_x(XB, wk + WK);
+        seq_xb = issued - 1;
+    }
+    // epilogue: wave (wk, wr) with wk < nf finishes fragment wk of row group wr: token lane & 15, rows 4 (lane >> 4) .. + 3
+    const int out_frag = wr * nf + wk;
+    const bool out_wave = wk < nf && out_frag < nfr;
+    const int out_row = loc.row0 + (out_wave ? out_frag : 0) * 16 + (lane >> 4) * 4;
+    u32x2 scv = dc_gload8((uint32_t)out_row * 2u, p.scales);
+    ++issued;
+    u32x2 biv{0u, 0u};
+    if (bias) {
+        biv = dc_gload8((uint32_t)out_row * 2u, bias);
+        ++issued;
+    }
+    DC_STAMP(6)   // everything requested
+    if (nck == 0) {   // a wave without a chunk (more waves along K than chunks) contributes zeros
+#pragma nounroll
+        for (int i = 0; i < nf; ++i)
+            *reinterpret_cast<f32x4 *>(smem + p.img_bytes + ((size_t)(wave * DC_UMAX + i) * 64 + lane) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    DC_STAMP(7)   // barrier: image built
+
+    // ---- units ------------------------------------------------------------------------------------------------------
+    const uint32_t img_lane = lds0 + (uint32_t)(lane & 15) * 16u;   // this lane's copy of entry 0
+    const uint32_t sel0 = 0x0c0c0400u, sel1 = 0x0c0c0500u, sel2 = 0x0c0c0600u, sel3 = 0x0c0c0700u;
+    auto chunk_pass = [&](DcX &X, int seq_x, int cc) {
+        dc_wait_vm(issued - 1 - seq_x);
+#define DC_XD(s) dc_landed(X.f[s]);
+        DC_XD(0) DC_XD(1) DC_XD(2) DC_XD(3) DC_XD(4) DC_XD(5) DC_XD(6) DC_XD(7)
+        DC_XD(8) DC_XD(9) DC_XD(10) DC_XD(11) DC_XD(12) DC_XD(13) DC_XD(14) DC_XD(15)
+#undef DC_XD
+        if (cc == 0) { DC_STAMP(8) }   // first chunk's activations landed
+        u32x4 B[16];   // the MFMA operands of the chunk's 16 k-steps
+#define DC_XF(m) B[2 * (m)] = dc_sel_ror8(X.f[2 * (m) + 1], X.f[2 * (m)], lo_lanes); B[2 * (m) + 1] = dc_sel_ror8(X.f[2 * (m)], X.f[2 * (m) + 1], hi_lanes);
+        DC_XF(0) DC_XF(1) DC_XF(2) DC_XF(3) DC_XF(4) DC_XF(5) DC_XF(6) DC_XF(7)
+#undef DC_XF
+        for (int i = 0; i < nf; ++i) {
+            const int u = cc * nf + i;
+            dc_wait_vm(issued - 1 - (3 * u + 2));
+            u32x4 cw = dc_lds_read16(stage0 + (uint32_t)u * 1024u + lane16);
+            u32x4 av = dc_lds_read16(stage0 + (uint32_t)i * 1024u + lane16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dc_landed(cw);
+            dc_landed(av);
+            f32x4 acc = __builtin_bit_cast(f32x4, av);
+            if (cc == 0) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            // gathers in batches of GD (all issued before the first MFMA waits; LDS reads return in order)
+            constexpr int GD = MULTI ? 8 : 16;
+            u32x4 a[GD];
+#define DC_G(s, sel) a[(s) % GD] = dc_lds_read16(__builtin_amdgcn_perm(cw[(s) >> 2], img_lane, sel));
+#define DC_M(s)                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(%1)\n\t; PQL %0" : "+v"(a[(s) % GD]) : "n"(GD - 1 - (s) % GD));  \
+    acc = Act<AT>::mfma16(__builtin_bit_cast(vec8, a[(s) % GD]), __builtin_bit_cast(vec8, B[s]), acc);  \
+    __builtin_amdgcn_sched_barrier(0);
+            DC_G(0, sel0) DC_G(1, sel1) DC_G(2, sel2) DC_G(3, sel3) DC_G(4, sel0) DC_G(5, sel1) DC_G(6, sel2) DC_G(7, sel3)
+            if constexpr (GD == 16) {
+                DC_G(8, sel0) DC_G(9, sel1) DC_G(10, sel2) DC_G(11, sel3) DC_G(12, sel0) DC_G(13, sel1) DC_G(14, sel2) DC_G(15, sel3)
+            }
+            DC_M(0) DC_M(1) DC_M(2) DC_M(3) DC_M(4) DC_M(5) DC_M(6) DC_M(7)
+            if constexpr (GD == 8) {
+                DC_G(8, sel0) DC_G(9, sel1) DC_G(10, sel2) DC_G(11, sel3) DC_G(12, sel0) DC_G(13, sel1) DC_G(14, sel2) DC_G(15, sel3)
+            }
+            DC_M(8) DC_M(9) DC_M(10) DC_M(11) DC_M(12) DC_M(13) DC_M(14) DC_M(15)
+#undef DC_G
+#undef DC_M
+            *reinterpret_cast<f32x4 *>(smem + p.img_bytes + ((size_t)(wave * DC_UMAX + i) * 64 + lane) * 16) = acc;
+        }
+    };
+    if constexpr (!MULTI) {
+        if (nck > 0) chunk_pass(XA, seq_xa, 0);
+    } else {
+        for (int cc = 0; cc < nck; cc += 2) {
+            chunk_pass(XA, seq_xa, cc);
+            if (cc + 2 < nck) {
+                issue_x(XA, wk + (cc + 2) * WK);
+                seq_xa = issued - 1;
+            }
+            if (cc + 1 < nck) {
+                chunk_pass(XB, seq_xb, cc + 1);
+                if (cc + 3 < nck) {
+                    issue_x(XB, wk + (cc + 3) * WK);
+                    seq_xb = issued - 1;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dc_landed(scv);
+    dc_landed(biv);
+    DC_STAMP(9)   // this wave's units done
+    __syncthreads();
+    DC_STAMP(10)   // all waves' units done
+
+    // ---- epilogue: the partial sums of the output fragment over the waves along K, in a fixed order -------------------
+    if (out_wave) {
+        const unsigned char *slot = smem + p.img_bytes + ((size_t)((wr << p.wk_log2) * DC_UMAX + wk) * 64 + lane) * 16;
+        f32x4 sum = *reinterpret_cast<const f32x4 *>(slot);
+#pragma nounroll
+        for (int w = 1; w < WK; ++w) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(slot + (size_t)w * (DC_UMAX * 1024));
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        const int t = lane & 15;
+        if (t < p.T) {
+            const uint32_t sw[2] = {scv.x, scv.y}, bw[2] = {biv.x, biv.y};
+            uint16_t h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint16_t s16 = (uint16_t)(sw[e >> 1] >> ((e & 1) * 16)), b16 = (uint16_t)(bw[e >> 1] >> ((e & 1) * 16));
+                h[e] = Act<AT>::from_f32(sum[e] * Act<AT>::to_f32(s16) + (bias ? Act<AT>::to_f32(b16) : 0.0f));
+            }
+            u32x2 o2;   // y and its row stride are 8-byte aligned (checked on the host)
+            o2.x = h[0] | ((uint32_t)h[1] << 16);
+            o2.y = h[2] | ((uint32_t)h[3] << 16);
+            *reinterpret_cast<u32x2 *>(p.y + (size_t)t * p.y_stride + out_row) = o2;
+        }
+    }
+    if constexpr (STAMPS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st[11] = __builtin_amdgcn_s_memrealtime();   // stores retired
+        const int nw = (int)(blockDim.x >> 6);
+        if (lane == 0 && (wave == 0 || wave == nw - 1)) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<uint16_t *>(p.bias)) +
+                                    (size_t)blockIdx.x * 24 + (wave == 0 ? 0 : 12);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) o[k] = st[k];
+        }
+    }
+#undef DC_STAMP
+}
+
+}  // namespace pq

@@ -11,6 +11,7 @@
 
 #include "pq_common.cuh"
 #include "pq_kernels.h"
+#include "pq_knobs.h"
 #include "pq_stream_geom.cuh"
 
 namespace pq {
@@ -95,12 +96,12 @@ static double stream_tall_model_us(const GemmArgs &a, int nf, int ksplit) {
 // `forced`: PQ_AMD_STREAM_KSPLIT (tests and tuning), 0 when unset.  Otherwise up to 4 blocks per tile when K has
 // at least 24 chunks, 2 from 16, and only up to 128 tokens (larger batches fill the chip without it).
 static int ksplit_limit(int T, int G, int M, int code_bytes, int *forced) {
-    const char *env = getenv("PQ_AMD_STREAM_KSPLIT");
+    const int env_split = knobs().stream_ksplit;
     const int cg = chunk_groups(code_bytes, M);
     const int nchunks = (G + cg - 1) / cg;
     int s = nchunks >= 24 ? 4 : nchunks >= 16 ? 2 : 1;
     *forced = 0;
-    if (env && *env) s = *forced = atoi(env);
+    if (env_split) s = *forced = env_split;
     if (T > 128) s = 1;
     if (s > nchunks) s = nchunks;
     s = s < 1 ? 1 : s > 8 ? 8 : s;
@@ -134,10 +135,9 @@ StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {
     int forced;
     const int smax = ksplit_limit(a.T, a.G, a.M, a.code_bytes, &forced);
     auto split_for = [&](int nf, int tf, int want) { return stream_ksplit_ok(a, nf, tf, want) ? want : 1; };
-    const char *env = getenv("PQ_AMD_STREAM_CFG");   // "NFxTF", for tuning
-    if (env && *env) {
-        int nf = 0, tf = 0;
-        if (sscanf(env, "%dx%d", &nf, &tf) == 2) {
+    if (knobs().stream_nf) {   // PQ_AMD_STREAM_CFG = "NFxTF", for tuning
+        const int nf = knobs().stream_nf, tf = knobs().stream_tf;
+        {
             const bool ok1 = tf == 1 && (nf == 1 || nf == 2 || (light && (nf == 4 || (packed && (nf == 7 || nf == 8)))));
             const bool okw = packed && ((nf == 4 && tf == 4 && light) || (nf == 4 && tf == 2) || (nf == 2 && tf == 4) ||
                                         (nf == 7 && tf == 2 && light));

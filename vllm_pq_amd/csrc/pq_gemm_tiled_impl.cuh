@@ -29,6 +29,7 @@
 #include "pq_common.cuh"
 #include "pq_gather.cuh"
 #include "pq_kernels.h"
+#include "pq_knobs.h"
 #include "pq_stream_geom.cuh"
 
 namespace pq {
@@ -834,10 +835,7 @@ static hipError_t tiled_launch_cfg(const GemmArgs &a, hipStream_t stream) {
         nslots = cus / 8;
         slots_cached[dev].store(nslots, std::memory_order_release);
     }
-    {
-        const char *env = getenv("PQ_AMD_TILED_SLOTS");   // tests and diagnosis: blocks per XCD (large: one tile per block)
-        if (env && atoi(env) > 0) nslots = atoi(env);
-    }
+    if (knobs().tiled_slots > 0) nslots = knobs().tiled_slots;   // tests and diagnosis: blocks per XCD (large: one tile per block)
     constexpr bool persist = D == 8 && M == 1;     // the kernel's PERSIST
     if (!persist || nslots > per_xcd) nslots = per_xcd;
     hipLaunchKernelGGL(kern, dim3(nslots * 8), dim3(TL_THREADS), lds, stream, static_cast<const uint16_t *>(a.x), a.T,
@@ -874,9 +872,8 @@ static TiledCfg tiled_cfg(const GemmArgs &a, int i) {
 }
 
 static int choose_tiled_cfg(const GemmArgs &a) {
-    const char *env = getenv("PQ_AMD_TILED_CFG");
-    if (env && *env) {
-        const int v = atoi(env);
+    if (knobs().tiled_cfg >= 0) {
+        const int v = knobs().tiled_cfg;
         if (v >= 0 && v < kNumTiledCfgs && (a.G * a.d) % (64 * tiled_step_tiles(a, tiled_cfg(a, v).kt)) == 0) return v;
     }
     // Shortest modelled launch: the blocks run in rounds of one per CU (every shape takes the whole LDS), a

@@ -63,6 +63,14 @@ bool gemm_stream_act_supported(const GemmArgs &a);
 int choose_stream_act_nf(const GemmArgs &a);
 hipError_t launch_gemm_stream_act(const GemmArgs &a, hipStream_t stream);
 
+// Decode batches (at most 16 tokens; d = 8, one codebook of up to 256 entries, one-byte packed codes, whole
+// 512-feature chunks): pq_gemm_decode_impl.cuh.  `waves` per block, of which 1 << wk_log2 along K; nf fragments
+// and c chunks per wave.  nf == 0: not taken.
+struct DecodeGeom { int nf, wk_log2, c, waves; };
+bool gemm_decode_supported(const GemmArgs &a);
+DecodeGeom choose_decode_geom(const GemmArgs &a);
+hipError_t launch_gemm_decode(const GemmArgs &a, hipStream_t stream);
+
 // Load-time re-layout of the codes for the MFMA kernels.
 bool stream_format_supported(int d, int K, int M, int code_bytes);
 bool packable(const Parts &parts, int d, int K, int M, int code_bytes);

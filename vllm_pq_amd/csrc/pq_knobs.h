@@ -1,0 +1,25 @@
+// Diagnostic knobs of the dispatch (tests, tuning tools): the PQ_AMD_* environment variables, read ONCE when the
+// library is first used and again only when pq_debug_reload_knobs() is called -- never per launch.
+//   PQ_AMD_FORCE_KERNEL   "generic" | "stream" | "tiled" | "decode"
+//   PQ_AMD_STREAM_CFG     "NFxTF" tile of the streaming kernel
+//   PQ_AMD_STREAM_KSPLIT  blocks per tile along K of the streaming kernel
+//   PQ_AMD_TILED_CFG      tile shape index of the tiled kernel
+//   PQ_AMD_TILED_SLOTS    blocks per XCD of the tiled kernel
+//   PQ_AMD_DECODE_CFG     "WAVESxNF" block shape of the decode kernel
+#pragma once
+
+namespace pq {
+
+struct Knobs {
+    int force_kernel;      // -1: none; else the dispatcher's kernel number
+    int stream_nf, stream_tf;   // 0: none
+    int stream_ksplit;     // 0: none
+    int tiled_cfg;         // -1: none
+    int tiled_slots;       // 0: none
+    int decode_waves, decode_nf;   // 0: none
+};
+
+const Knobs &knobs();      // thread-safe; the first call reads the environment
+void reload_knobs();       // re-reads the environment; not to be called while another thread launches
+
+}  // namespace pq
