@@ -131,10 +131,13 @@ __global__ __launch_bounds__(512) void xpat2_k(const unsigned char *x, unsigned 
     unsigned long long s0 = rt();
     const int q = lane >> 4, c = lane & 15;
     u32x4 v[16];
-    if (mode == 0) {
-        const unsigned char *base = x + (size_t)(c & 7) * pitch + wave * 1024 + (q + 4 * (c >> 3)) * 16;
+    if (mode == 0 || mode >= 2) {
+        // mode 2: the wave's chunk rotated by the block index; mode 3: also the line order within the chunk
+        const int wv = mode >= 2 ? (wave + blockIdx.x) & 7 : wave;
+        const int rot = mode == 3 ? (blockIdx.x >> 3) & 7 : 0;
+        const unsigned char *base = x + (size_t)(c & 7) * pitch + wv * 1024 + (q + 4 * (c >> 3)) * 16;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const u32x4 *>(base + (size_t)(i & 1) * 8 * pitch + (i >> 1) * 128);
+        for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const u32x4 *>(base + (size_t)(i & 1) * 8 * pitch + (((i >> 1) + rot) & 7) * 128);
     } else {   // 4 rows x 256 bytes: token (c & 3) + 4 (i & 3), piece q + 4 (c >> 2)
         const unsigned char *base = x + (size_t)(c & 3) * pitch + wave * 1024 + (q + 4 * (c >> 2)) * 16;
 #pragma unroll
@@ -299,14 +302,15 @@ int main() {
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 printf("   back to back: %.2f us/launch\n", ms * 1e3 / 200);
             }
-            for (int mode : {0, 1}) {
+            for (int mode : {0, 1, 2, 3}) {
                 for (int i = 0; i < 6; ++i) {
                     hipLaunchKernelGGL(xpat2_k, dim3(NB), dim3(512), 0, 0, xb, 8192u, mode, st, sink);
                     CK(hipDeviceSynchronize());
                 }
                 CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
                 report(mode == 0 ? "xpat2: 8 rows x 128 B per load, 16 loads per wave, row pitch 8192 B"
-                                 : "xpat2: 4 rows x 256 B per load, 16 loads per wave, row pitch 8192 B", h, NB, 4, n2);
+                       : mode == 1 ? "xpat2: 4 rows x 256 B per load, 16 loads per wave, row pitch 8192 B"
+                       : mode == 2 ? "xpat2: 8 rows x 128 B, chunk rotated by block" : "xpat2: 8 rows x 128 B, chunk and line rotated by block", h, NB, 4, n2);
                 CK(hipEventRecord(e0));
                 for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(xpat2_k, dim3(NB), dim3(512), 0, 0, xb, 8192u, mode, st, sink);
                 CK(hipEventRecord(e1));

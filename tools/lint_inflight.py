@@ -6,6 +6,9 @@ them with hand-counted s_waitcnt.  Between such an instruction ("; PQI <reg>" pr
 the point from which its destination may be read ("; PQL <reg>"), the compiler must neither read nor write that
 register -- it would read stale data, or have its value overwritten when the load returns -- and control must
 not branch (a copy could be inserted at a join or a back edge, and this linear scan could not follow it).
+A load announced by "; PQX <reg>" is meant to stay in flight across branches (a prologue that requests its
+operands before it builds tables under run-time conditions): for those registers the branch rule is waived, and the
+read / write rule holds for every instruction between issue and landing in text order, whatever the control flow.
 
   python tools/lint_inflight.py build/*.s      exit status 1 on any violation
 """
@@ -27,20 +30,23 @@ def regs_of(text):
 
 def lint(path):
     bad = 0
-    func, inflight, pending_issue = None, {}, None
+    func, inflight, pending_issue, across = None, {}, None, set()
     for ln, raw in enumerate(open(path), 1):
         line = raw.strip()
         if not line:
             continue
         if raw[0] not in " \t" and line.endswith(":") and not line.startswith("."):
-            func, inflight, pending_issue = line[:-1], {}, None
+            func, inflight, pending_issue, across = line[:-1], {}, None, set()
             continue
-        if line.startswith("; PQI"):
+        if line.startswith("; PQI") or line.startswith("; PQX"):
             pending_issue = regs_of(line)
+            if line.startswith("; PQX"):
+                across |= pending_issue
             continue
         if line.startswith("; PQL"):
             for r in regs_of(line):
                 inflight.pop(r, None)
+                across.discard(r)
             continue
         if line.startswith(";") or line.startswith("."):
             continue
@@ -66,10 +72,12 @@ def lint(path):
         if not inflight:
             continue
         if op.startswith("s_cbranch") or op in ("s_branch", "s_setpc_b64", "s_endpgm"):
-            print(f"{path}:{ln}: [{func}] {op} with loads in flight into v{sorted(inflight)}")
-            bad += 1
+            held = set(inflight) - across if op != "s_endpgm" else set(inflight)
+            if held:
+                print(f"{path}:{ln}: [{func}] {op} with loads in flight into v{sorted(held)}")
+                bad += 1
             if op == "s_endpgm":
-                inflight = {}
+                inflight, across = {}, set()
             continue
         hit = regs_of(code) & set(inflight)
         if hit:

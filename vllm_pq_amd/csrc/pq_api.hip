@@ -64,7 +64,7 @@ Kernel choose(const pq::GemmArgs &a) {
     if (force == K_STREAM && pq::gemm_stream_supported(a)) return K_STREAM;
     if (force == K_TILED && pq::gemm_tiled_supported(a)) return K_TILED;
     if (force == K_DECODE && pq::gemm_decode_supported(a)) return K_DECODE;
-    if (force < 0 && pq::gemm_decode_supported(a)) return K_DECODE;
+    if (force < 0 && pq::gemm_decode_preferred(a)) return K_DECODE;
     const bool st = pq::gemm_stream_supported(a);
     const bool ti = pq::gemm_tiled_supported(a);
     if (ti && st && a.T > 16) {

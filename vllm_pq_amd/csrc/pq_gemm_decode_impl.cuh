@@ -21,8 +21,10 @@
 //    slot its codes came in, so the loop body does not depend on the fragment either.
 //
 // Work split: a block of WK x WR waves owns WR * nf fragments (16 rows each) of one output partition and all of
-// K; wave (wk, wr) takes chunks wk, wk + WK, ... of fragments wr * nf .. + nf - 1.  The activations of a chunk
-// (16 x 16 bytes per lane) are loaded once per chunk and reused by the nf fragments.
+// K (at most 8 chunks of 512 features: K <= 4096); wave (wk, wr) takes chunk wk of fragments wr * nf .. + nf - 1.
+// The activations of the chunk (16 x 16 bytes per lane) are loaded once and reused by the nf fragments.
+// Every block reads all of x: 16 tokens x K x 2 bytes at the 55-65 GB/s a CU takes from L2, 2 us at K = 4096 --
+// the largest single cost of the launch, and why longer K goes to the streaming kernel, which splits K over blocks.
 #pragma once
 #include "pq_common.cuh"
 #include "pq_kernels.h"
@@ -43,18 +45,20 @@ struct DecodeParams {
     int64_t y_stride;              // elements
     uint32_t x_stride_bytes;
     int T;
-    int nchunks;                   // 512-feature chunks of K
+    int nchunks;                   // 512-feature chunks of K (at most 1 << wk_log2)
     int K;                         // codebook entries (power of two, 16 .. 256)
     int nf;                        // fragments per wave
     int wk_log2;                   // log2 of the waves along K
     uint32_t img_bytes;            // K * 256, the staging area follows
+    int spt;                       // 16-byte image slots per thread: max(1, K * 16 / threads per block)
     TileMap tmap;                  // tiles of (blockDim/64 >> wk_log2) * nf * 16 rows
 };
 
 // ---- hand-issued memory instructions -------------------------------------------------------------------------
-// The compiler tracks none of these; every wait is counted by hand.  "; PQX" marks a global load whose register
-// stays in flight across branches (checked over the whole kernel: nothing but such loads and MFMAs may touch
-// it), "; PQI" / "; PQL" an LDS read and the point from which its register may be read (no branch in between).
+// The compiler tracks none of these; every wait is counted by hand.  "; PQX" marks a load or LDS read whose
+// register stays in flight across branches and loop back edges, "; PQL" the point from which the register may be
+// read: tools/lint_inflight.py checks in the generated assembly that no instruction in between, in text order,
+// touches it.
 template <int OFF>
 __device__ __forceinline__ u32x4 dc_gload16(uint32_t voff, const unsigned char *sbase) {
     u32x4 v;
@@ -72,7 +76,7 @@ __device__ __forceinline__ void dc_dma16(uint32_t lds_addr, uint32_t voff, const
 }
 __device__ __forceinline__ u32x4 dc_lds_read16(uint32_t addr) {
     u32x4 v;
-    asm volatile("; PQI %0\n\tds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    asm volatile("; PQX %0\n\tds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
 template <typename V>
@@ -118,9 +122,8 @@ __device__ __forceinline__ u32x4 dc_sel_ror8(const u32x4 &a, const u32x4 &b, uin
 
 struct DcX { u32x4 f[16]; };   // the activations of one chunk: k-step s of lane (t, q) = x[t][chunk * 512 + 32 s + 8 q .. + 7]
 
-// MULTI: a wave may own more than one chunk (a second activation register set, loaded one chunk ahead)
 // STAMPS (diagnostic builds only): thread 0 writes wall-clock stamps of the phases to `bias` (8 x u64 per block)
-template <typename AT, bool MULTI, bool STAMPS = false>
+template <typename AT, bool STAMPS = false>
 __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const DecodeParams p) {
     typedef typename Act<AT>::vec8 vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -139,81 +142,106 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
         st[0] = __builtin_amdgcn_s_memrealtime();
     }
 #define DC_STAMP(k) if constexpr (STAMPS) { asm volatile("" ::: "memory"); st[k] = __builtin_amdgcn_s_memrealtime(); asm volatile("" ::: "memory"); }
+
+    // A launch of a few microseconds is paced by the instructions its waves issue (a wave issues one every 4-5
+    // cycles at best, the two waves of a SIMD share the scalar unit, and code that runs once is fetched at a
+    // third of that rate) and by two data streams: the code pieces from HBM, and the activations from L2 --
+    // every block reads all of x, 32 MB of L2 reads for 256 blocks at 16 tokens and K = 4096, about 2 us at the
+    // 55 - 65 GB/s a CU takes in.  The memory pipeline of a CU returns data in request order across all its waves.
+    // So: every wave requests its activations first, the codebook image is stored while they arrive, and the code
+    // pieces (HBM latency) are requested only once every wave of the block has its activation loads queued.
     const int WK = 1 << p.wk_log2;
     const int wk = wave & (WK - 1), wr = wave >> p.wk_log2;
     const int nf = p.nf;
+    const int nck = wk < p.nchunks ? 1 : 0;                   // a wave beyond the last chunk has no work
+    const int U = nck * nf;                                   // its units (at most DC_UMAX)
+
+    // ---- the block's tile
     const int frags_blk = (int)((blockDim.x >> 6) >> p.wk_log2) * nf;
     const TileLoc loc = locate_tile(p.tmap, (int)blockIdx.x, frags_blk * 16);
     const int nfr = loc.nrows >> 4;                       // valid fragments of the tile (partitions are multiples of 16 rows)
-    const int f0 = loc.row0 >> 4;
-    const int nck = (p.nchunks - wk + WK - 1) >> p.wk_log2;   // chunks of this wave: wk, wk + WK, ...
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const uint32_t stage0 = lds0 + p.img_bytes + (uint32_t)wave * (DC_UMAX * 1024);   // this wave's staging slots
     const uint32_t lane16 = (uint32_t)lane * 16u;
-
-    // ---- requests.  The memory pipeline of a CU returns data in request order across ALL its waves, and the
-    // activation loads (16 rows x 64 bytes per wave-instruction) are what it spends most of its time on: 128 KiB
-    // at 16 tokens and K = 4096, 2.2 us.  So the code pieces (HBM) are requested in between them, one behind every
-    // second activation load: their latency and the HBM stream then run while the pipeline works through the
-    // activations, and everything has landed shortly after the last activation load has.
-    // Sequence numbers (codebook entries not counted): activation load s of the first chunk sits at
-    // s + min(U, s / 2), code piece j at 3 j + 2; then the second chunk's activations (MULTI), scales, bias.
-    const int U = nck * nf;                           // this wave's units (at most DC_UMAX)
     DC_STAMP(1)   // tile found
+
+    // ---- codebook entries: entry e fills 16 image slots of 16 bytes (one per lane residue); a thread owns spt
+    // consecutive slots
     int issued = 0;
-    // codebook image: entry e fills 16 slots of 16 bytes (one per lane residue); a thread owns spt consecutive slots
-    const int nthreads = (int)blockDim.x;
-    const int slots = p.K << 4;
-    const int spt = slots >= nthreads ? slots / nthreads : 1;
-    const bool img_active = tid * spt < slots;
+    const int spt = p.spt;
+    const bool img_active = tid * spt < (p.K << 4);
     const int ncb = spt > 16 ? spt >> 4 : 1;          // entries per thread (blocks of one or two waves: up to 4)
-    const int spe = spt > 16 ? 16 : spt;              // slots of one entry that this thread writes
     const int e0 = img_active ? (tid * spt) >> 4 : 0;
     const unsigned char *cb_part = p.codebooks + (size_t)loc.part * p.K * 16;
-    u32x4 cbv0 = dc_gload16<0>((uint32_t)e0 * 16u, cb_part), cbv1{0u, 0u, 0u, 0u}, cbv2{0u, 0u, 0u, 0u}, cbv3{0u, 0u, 0u, 0u};
-    if (ncb > 1) {
+    u32x4 cbv0 = dc_gload16<0>((uint32_t)e0 * 16u, cb_part), cbv1, cbv2, cbv3;
+    if (ncb > 1) {   // always four loads then (a block of two waves re-reads its two entries: same addresses, no traffic)
         cbv1 = dc_gload16<16>((uint32_t)e0 * 16u, cb_part);
-        if (ncb > 2) {
-            cbv2 = dc_gload16<32>((uint32_t)e0 * 16u, cb_part);
-            cbv3 = dc_gload16<48>((uint32_t)e0 * 16u, cb_part);
-        }
+        cbv2 = dc_gload16<0>((uint32_t)(e0 + (ncb > 2 ? 2 : 0)) * 16u, cb_part);
+        cbv3 = dc_gload16<16>((uint32_t)(e0 + (ncb > 2 ? 2 : 0)) * 16u, cb_part);
+        issued += 4;
+    } else {
+        ++issued;
     }
-    // Activations.  MFMA k-step s wants lane (q = l >> 4, c = l & 15) to hold x[token c][32 s + 8 q .. + 7]: 16 rows x 64
-    // bytes per wave-load, which the memory pipeline serves four times slower than whole 128-byte lines.  So a
-    // pair of loads fetches one line (two k-steps) of tokens 0..7 and of tokens 8..15: lane (q, c) takes piece
-    // q + 4 (c >> 3) of token (c & 7) [+ 8]; the two k-steps' operands are then one row-local select each
-    // (dc_sel_ror8): k-step 2m = lanes c < 8 of the first load | lanes c - 8 of the second, k-step 2m + 1 the rest.
+
+    // ---- activations and code pieces.  MFMA k-step s wants lane (q = l >> 4, c = l & 15) to hold
+    // x[token c][32 s + 8 q .. + 7]: 16 rows x 64 bytes per wave-load, which the memory pipeline serves far slower than
+    // whole 128-byte lines.  So a pair of loads fetches one line (two k-steps) of tokens 0..7 and of tokens 8..15:
+    // lane (q, c) takes piece q + 4 (c >> 3) of token (c & 7) [+ 8]; the two k-steps' operands are then one
+    // row-local select each (dc_sel_ror8): k-step 2m = lanes c < 8 of the first load | lanes c - 8 of the second,
+    // k-step 2m + 1 the rest.
+    // Unit i is chunk wk of fragment wr * nf + i of the tile (fragments past the tile's last repeat it and are
+    // never stored); its piece goes by DMA straight into staging slot i of the wave.
     const int xc = lane & 7;
     const uint32_t xpiece = (uint32_t)((lane >> 4) + 4 * ((lane >> 3) & 1)) * 16u;
     const uint32_t xoff_a = (uint32_t)(xc < p.T ? xc : p.T - 1) * p.x_stride_bytes + xpiece;
     const uint32_t xoff_b = (uint32_t)(xc + 8 < p.T ? xc + 8 : p.T - 1) * p.x_stride_bytes + xpiece;
     const uint64_t lo_lanes = 0x00ff00ff00ff00ffull, hi_lanes = 0xff00ff00ff00ff00ull;
-    // unit j = cc * nf + i is chunk wk + cc * WK of fragment wr * nf + i (clamped to the tile); its piece goes to slot j
-    int dma_j = 0, dma_i = 0;
+    int fb = wr * nf, nvalid = nfr - fb;           // first fragment of the wave, fragments it really has
+    if (nvalid < 1) { fb = nfr - 1; nvalid = 1; }
     const size_t frag_bytes = (size_t)p.nchunks * 1024;
-    const unsigned char *dma_chunk = p.codes + (size_t)wk * 1024;
-    auto issue_dma = [&]() {
-        if (dma_j < U) {
-            const int fi = wr * nf + dma_i;
-            dc_dma16(stage0 + (uint32_t)dma_j * 1024u, lane16, dma_chunk + (size_t)(f0 + (fi < nfr ? fi : nfr - 1)) * frag_bytes);
-            ++dma_j;
-            ++issued;
-            if (++dma_i == nf) {
-                dma_i = 0;
-                dma_chunk += (size_t)WK * 1024;
-            }
+    const unsigned char *dma_src = p.codes + ((size_t)((loc.row0 >> 4) + fb) * p.nchunks + wk) * 1024;
+    uint32_t dma_dst = stage0;
+    int dma_i = 0;
+    auto issue_dma = [&](int j) {
+        if (j < U) {
+            dc_dma16(dma_dst, lane16, dma_src);
+            dma_dst += 1024;
+            ++dma_i;
+            if (dma_i < nvalid) dma_src += frag_bytes;
         }
     };
-    auto put_image = [&]() {
-        if (img_active) {
+    DcX XA;
+    const unsigned char *xb0 = p.x + (size_t)(wk < p.nchunks ? wk : p.nchunks - 1) * 1024;
+#define DC_XP(m) XA.f[2 * (m)] = dc_gload16<128 * (m)>(xoff_a, xb0); XA.f[2 * (m) + 1] = dc_gload16<128 * (m)>(xoff_b, xb0);
+    DC_XP(0) DC_XP(1) DC_XP(2) DC_XP(3) DC_XP(4) DC_XP(5) DC_XP(6) DC_XP(7)
+#undef DC_XP
+    issued += 16;
+    const int seq_xa = issued - 1;                // sequence number of the set's last load
+    DC_STAMP(2)   // entries and activations requested
+
+    // ---- codebook image, stored while the memory pipeline works through the activation loads
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the entries are the oldest requests: 16 loads behind them
+    dc_landed(cbv0);
+    DC_STAMP(3)   // entries landed
+    if (img_active) {
+        if (spt == 8) {
+            // 256 entries, 512 threads: the thread's 8 slots, in an order permuted per lane (slot c ^ (tid & 7)) so
+            // that the lanes of a store group land on different banks
+            const uint32_t a0 = (uint32_t)tid * 128u + ((uint32_t)(tid & 7) << 4);
+#define DC_IS(c) *reinterpret_cast<u32x4 *>(smem + (a0 ^ ((c) << 4))) = cbv0;
+            DC_IS(0) DC_IS(1) DC_IS(2) DC_IS(3) DC_IS(4) DC_IS(5) DC_IS(6) DC_IS(7)
+#undef DC_IS
+        } else {
+            const int spe = spt > 16 ? 16 : spt;              // slots of one entry that this thread writes
             auto put = [&](const u32x4 &v, int base) {
 #pragma nounroll
-                for (int c = 0; c < spe; ++c)    // rotated per thread so that a store group's lanes land on different banks
+                for (int c = 0; c < spe; ++c)
                     *reinterpret_cast<u32x4 *>(smem + (size_t)(base + ((c + tid) & (spe - 1))) * 16) = v;
             };
             const int first = tid * spt;
             put(cbv0, first);
             if (ncb > 1) {
+                dc_landed(cbv1); dc_landed(cbv2); dc_landed(cbv3);
                 put(cbv1, first + 16);
                 if (ncb > 2) {
                     put(cbv2, first + 32);
@@ -221,125 +249,104 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
                 }
             }
         }
-    };
-    DcX XA, XB;
-    const unsigned char *xb0 = p.x + (size_t)(wk < p.nchunks ? wk : p.nchunks - 1) * 1024;
-#define DC_XL(s) XA.f[s] = dc_gload16<128 * ((s) >> 1)>((s) & 1 ? xoff_b : xoff_a, xb0); ++issued;
-    DC_XL(0) DC_XL(1) issue_dma();
-    DC_XL(2) DC_XL(3) issue_dma();
-    DC_XL(4) DC_XL(5) issue_dma();
-    DC_XL(6) DC_XL(7) issue_dma();
-    // the codebook entries are older than everything counted in `issued`: they have landed when no more than that is
-    // outstanding; the image is stored while the pipeline works through the requests made so far
-    DC_STAMP(2)   // first half requested
-    dc_wait_vm(issued);
-    DC_STAMP(3)   // codebook entries landed
-    dc_landed(cbv0); dc_landed(cbv1); dc_landed(cbv2); dc_landed(cbv3);
-    put_image();
-    DC_STAMP(4)   // image stored
-    DC_XL(8) DC_XL(9) issue_dma();
-    DC_XL(10) DC_XL(11) issue_dma();
-    DC_XL(12) DC_XL(13) issue_dma();
-    DC_XL(14) DC_XL(15) issue_dma();
-#undef DC_XL
-    int seq_xa = 15 + (U < 7 ? U : 7), seq_xb = 0;    // sequence number of the set's last load
-    auto issue_x = [&](DcX &X, int chunk) {
-        const unsigned char *xb = p.x + (size_t)(chunk < p.nchunks ? chunk : p.nchunks - 1) * 1024;
-#define DC_XL(s) X.f[s] = dc_gload16<128 * ((s) >> 1)>((s) & 1 ? xoff_b : xoff_a, xb);
-        DC_XL(0) DC_XL(1) DC_XL(2) DC_XL(3) DC_XL(4) DC_XL(5) DC_XL(6) DC_XL(7)
-        DC_XL(8) DC_XL(9) DC_XL(10) DC_XL(11) DC_XL(12) DC_XL(13) DC_XL(14) DC_XL(15)
-#undef DC_XL
-        issued += 16;
-    };
-    DC_STAMP(5)   // first chunk's activations and the codes requested
-    if constexpr (MULTI) {
-        issue_x(XB, wk + WK);
-        seq_xb = issued - 1;
     }
-    // epilogue: wave (wk, wr) with wk < nf finishes fragment wk of row group wr: token lane & 15, rows 4 (lane >> 4) .. + 3
-    const int out_frag = wr * nf + wk;
-    const bool out_wave = wk < nf && out_frag < nfr;
-    const int out_row = loc.row0 + (out_wave ? out_frag : 0) * 16 + (lane >> 4) * 4;
-    u32x2 scv = dc_gload8((uint32_t)out_row * 2u, p.scales);
-    ++issued;
-    u32x2 biv{0u, 0u};
-    if (bias) {
-        biv = dc_gload8((uint32_t)out_row * 2u, bias);
-        ++issued;
-    }
-    DC_STAMP(6)   // everything requested
     if (nck == 0) {   // a wave without a chunk (more waves along K than chunks) contributes zeros
 #pragma nounroll
         for (int i = 0; i < nf; ++i)
             *reinterpret_cast<f32x4 *>(smem + p.img_bytes + ((size_t)(wave * DC_UMAX + i) * 64 + lane) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    DC_STAMP(4)   // image stored
+    // One barrier does two things: the image is complete, and every wave of the block has requested its
+    // activations -- a code piece (HBM) requested before that would hold the activations of the slower waves back by
+    // an HBM latency (returns are in request order across the waves of a CU).
     __syncthreads();
-    DC_STAMP(7)   // barrier: image built
+    DC_STAMP(5)   // barrier
 
-    // ---- units ------------------------------------------------------------------------------------------------------
-    const uint32_t img_lane = lds0 + (uint32_t)(lane & 15) * 16u;   // this lane's copy of entry 0
-    const uint32_t sel0 = 0x0c0c0400u, sel1 = 0x0c0c0500u, sel2 = 0x0c0c0600u, sel3 = 0x0c0c0700u;
-    auto chunk_pass = [&](DcX &X, int seq_x, int cc) {
+    // ---- code pieces, epilogue operands
+    const int seq_dma0 = issued;
+#pragma nounroll
+    for (int j = 0; j < U; ++j) issue_dma(j);
+    issued += U;
+    // wave (wk, wr) with wk < nf finishes fragment wk of row group wr: token lane & 15, rows 4 (lane >> 4) .. + 3
+    const int out_frag = wr * nf + wk;
+    const bool out_wave = wk < nf && out_frag < nfr;
+    const int out_row = loc.row0 + (out_wave ? out_frag : 0) * 16 + (lane >> 4) * 4;
+    u32x2 scv = dc_gload8((uint32_t)out_row * 2u, p.scales);
+    ++issued;
+    u32x2 biv = dc_gload8((uint32_t)out_row * 2u, bias ? bias : p.scales);   // without a bias: loaded, never used
+    ++issued;
+    DC_STAMP(6)   // everything requested
+
+    // the first chunk's activations: wait, and permute them into the MFMA operands of its 16 k-steps
+    auto prepare = [&](DcX &X, int seq_x, u32x4 (&B)[16]) {
         dc_wait_vm(issued - 1 - seq_x);
 #define DC_XD(s) dc_landed(X.f[s]);
         DC_XD(0) DC_XD(1) DC_XD(2) DC_XD(3) DC_XD(4) DC_XD(5) DC_XD(6) DC_XD(7)
         DC_XD(8) DC_XD(9) DC_XD(10) DC_XD(11) DC_XD(12) DC_XD(13) DC_XD(14) DC_XD(15)
 #undef DC_XD
-        if (cc == 0) { DC_STAMP(8) }   // first chunk's activations landed
-        u32x4 B[16];   // the MFMA operands of the chunk's 16 k-steps
 #define DC_XF(m) B[2 * (m)] = dc_sel_ror8(X.f[2 * (m) + 1], X.f[2 * (m)], lo_lanes); B[2 * (m) + 1] = dc_sel_ror8(X.f[2 * (m)], X.f[2 * (m) + 1], hi_lanes);
         DC_XF(0) DC_XF(1) DC_XF(2) DC_XF(3) DC_XF(4) DC_XF(5) DC_XF(6) DC_XF(7)
 #undef DC_XF
-        for (int i = 0; i < nf; ++i) {
-            const int u = cc * nf + i;
-            dc_wait_vm(issued - 1 - (3 * u + 2));
-            u32x4 cw = dc_lds_read16(stage0 + (uint32_t)u * 1024u + lane16);
-            u32x4 av = dc_lds_read16(stage0 + (uint32_t)i * 1024u + lane16);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            dc_landed(cw);
-            dc_landed(av);
-            f32x4 acc = __builtin_bit_cast(f32x4, av);
-            if (cc == 0) acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            // gathers in batches of GD (all issued before the first MFMA waits; LDS reads return in order)
-            constexpr int GD = MULTI ? 8 : 16;
-            u32x4 a[GD];
-#define DC_G(s, sel) a[(s) % GD] = dc_lds_read16(__builtin_amdgcn_perm(cw[(s) >> 2], img_lane, sel));
-#define DC_M(s)                                                                                    \
-    asm volatile("s_waitcnt lgkmcnt(%1)\n\t; PQL %0" : "+v"(a[(s) % GD]) : "n"(GD - 1 - (s) % GD));  \
-    acc = Act<AT>::mfma16(__builtin_bit_cast(vec8, a[(s) % GD]), __builtin_bit_cast(vec8, B[s]), acc);  \
+    };
+    u32x4 B0[16];
+    prepare(XA, seq_xa, B0);
+    DC_STAMP(7)   // activations landed and permuted
+
+    // ---- units ------------------------------------------------------------------------------------------------------
+    const uint32_t img_lane = lds0 + (uint32_t)(lane & 15) * 16u;   // this lane's copy of entry 0
+    const uint32_t sel0 = 0x0c0c0400u, sel1 = 0x0c0c0500u, sel2 = 0x0c0c0600u, sel3 = 0x0c0c0700u;
+    // The wave's units, software-pipelined over two sets of 8 gathered weight fragments: while the MFMAs of one
+    // half of a unit's k-steps run, the gathers of the other half (or of the next unit's first half) are in flight,
+    // so the LDS and the matrix pipe work at the same time.  LDS reads return in order; every count below is the
+    // number of reads issued behind the one waited for.
+    auto units = [&](const u32x4 (&B)[16]) {
+        u32x4 a0[8], a1[8];
+        dc_wait_vm(issued - 1 - seq_dma0);
+        u32x4 cw = dc_lds_read16(stage0 + lane16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dc_landed(cw);
+#define DC_G(A, j, s, sel) A[j] = dc_lds_read16(__builtin_amdgcn_perm(cw[(s) >> 2], img_lane, sel));
+#define DC_GLO DC_G(a0, 0, 0, sel0) DC_G(a0, 1, 1, sel1) DC_G(a0, 2, 2, sel2) DC_G(a0, 3, 3, sel3) DC_G(a0, 4, 4, sel0) DC_G(a0, 5, 5, sel1) DC_G(a0, 6, 6, sel2) DC_G(a0, 7, 7, sel3)
+#define DC_GHI DC_G(a1, 0, 8, sel0) DC_G(a1, 1, 9, sel1) DC_G(a1, 2, 10, sel2) DC_G(a1, 3, 11, sel3) DC_G(a1, 4, 12, sel0) DC_G(a1, 5, 13, sel1) DC_G(a1, 6, 14, sel2) DC_G(a1, 7, 15, sel3)
+#define DC_MW(j, s, n)                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(%1)\n\t; PQL %0" : "+v"(a0[j]) : "n"(n));               \
+    acc = Act<AT>::mfma16(__builtin_bit_cast(vec8, a0[j]), __builtin_bit_cast(vec8, B[s]), acc); \
     __builtin_amdgcn_sched_barrier(0);
-            DC_G(0, sel0) DC_G(1, sel1) DC_G(2, sel2) DC_G(3, sel3) DC_G(4, sel0) DC_G(5, sel1) DC_G(6, sel2) DC_G(7, sel3)
-            if constexpr (GD == 16) {
-                DC_G(8, sel0) DC_G(9, sel1) DC_G(10, sel2) DC_G(11, sel3) DC_G(12, sel0) DC_G(13, sel1) DC_G(14, sel2) DC_G(15, sel3)
-            }
-            DC_M(0) DC_M(1) DC_M(2) DC_M(3) DC_M(4) DC_M(5) DC_M(6) DC_M(7)
-            if constexpr (GD == 8) {
-                DC_G(8, sel0) DC_G(9, sel1) DC_G(10, sel2) DC_G(11, sel3) DC_G(12, sel0) DC_G(13, sel1) DC_G(14, sel2) DC_G(15, sel3)
-            }
-            DC_M(8) DC_M(9) DC_M(10) DC_M(11) DC_M(12) DC_M(13) DC_M(14) DC_M(15)
-#undef DC_G
-#undef DC_M
+#define DC_MN(j, s)                                                                       \
+    acc = Act<AT>::mfma16(__builtin_bit_cast(vec8, a1[j]), __builtin_bit_cast(vec8, B[s]), acc); \
+    __builtin_amdgcn_sched_barrier(0);
+        DC_GLO
+#pragma nounroll
+        for (int i = 0; i < nf; ++i) {
+            f32x4 acc{0.f, 0.f, 0.f, 0.f};
+            DC_GHI
+            // the next unit's codes (the last unit reads its own again: same counts, no branch)
+            const int in = i + 1 < nf ? i + 1 : i;
+            dc_wait_vm(issued - 1 - (seq_dma0 + in));
+            u32x4 cwn = dc_lds_read16(stage0 + (uint32_t)in * 1024u + lane16);
+            // behind a0[j]: 7 - j of its set, the store of the unit before, 8 of the other set, the read above
+            DC_MW(0, 0, 15) DC_MW(1, 1, 15) DC_MW(2, 2, 14) DC_MW(3, 3, 13) DC_MW(4, 4, 12) DC_MW(5, 5, 11) DC_MW(6, 6, 10) DC_MW(7, 7, 9)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dc_landed(cwn);
+#define DC_L1(j) dc_landed(a1[j]);
+            DC_L1(0) DC_L1(1) DC_L1(2) DC_L1(3) DC_L1(4) DC_L1(5) DC_L1(6) DC_L1(7)
+#undef DC_L1
+            cw = cwn;
+            DC_GLO                       // first half of the next unit (of this one again after the last: never used)
+            DC_MN(0, 8) DC_MN(1, 9) DC_MN(2, 10) DC_MN(3, 11) DC_MN(4, 12) DC_MN(5, 13) DC_MN(6, 14) DC_MN(7, 15)
             *reinterpret_cast<f32x4 *>(smem + p.img_bytes + ((size_t)(wave * DC_UMAX + i) * 64 + lane) * 16) = acc;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the gathers issued behind the last unit
+#define DC_L0(j) dc_landed(a0[j]);
+        DC_L0(0) DC_L0(1) DC_L0(2) DC_L0(3) DC_L0(4) DC_L0(5) DC_L0(6) DC_L0(7)
+#undef DC_L0
+#undef DC_G
+#undef DC_GLO
+#undef DC_GHI
+#undef DC_MW
+#undef DC_MN
     };
-    if constexpr (!MULTI) {
-        if (nck > 0) chunk_pass(XA, seq_xa, 0);
-    } else {
-        for (int cc = 0; cc < nck; cc += 2) {
-            chunk_pass(XA, seq_xa, cc);
-            if (cc + 2 < nck) {
-                issue_x(XA, wk + (cc + 2) * WK);
-                seq_xa = issued - 1;
-            }
-            if (cc + 1 < nck) {
-                chunk_pass(XB, seq_xb, cc + 1);
-                if (cc + 3 < nck) {
-                    issue_x(XB, wk + (cc + 3) * WK);
-                    seq_xb = issued - 1;
-                }
-            }
-        }
-    }
+    if (nck > 0) units(B0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dc_landed(scv);
     dc_landed(biv);

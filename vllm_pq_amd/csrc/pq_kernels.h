@@ -68,6 +68,7 @@ hipError_t launch_gemm_stream_act(const GemmArgs &a, hipStream_t stream);
 // and c chunks per wave.  nf == 0: not taken.
 struct DecodeGeom { int nf, wk_log2, c, waves; };
 bool gemm_decode_supported(const GemmArgs &a);
+bool gemm_decode_preferred(const GemmArgs &a);
 DecodeGeom choose_decode_geom(const GemmArgs &a);
 hipError_t launch_gemm_decode(const GemmArgs &a, hipStream_t stream);
 
