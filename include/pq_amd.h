@@ -120,6 +120,13 @@ int pq_embedding(const int64_t *ids, int32_t T, const void *codes, const void *c
  */
 size_t pq_gemm_workspace_bytes(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d,
                                int32_t code_bytes, int32_t dtype);
+/*
+ * The largest value pq_gemm_workspace_bytes returns for any problem (16 KiB of counters + 8 MiB of partial sums):
+ * a buffer of this size, allocated once per stream that issues calls, serves every layer and batch size, so a host
+ * never has to grow (and thereby replace) a workspace that launches already captured into a HIP graph point to.
+ * A problem whose preferred split would need more runs with the largest split that fits.  No reference counterpart.
+ */
+size_t pq_gemm_workspace_max_bytes(void);
 
 /*
  * y[t][n] = act( scales[n] * sum_k x[t][k] * Wunscaled[n][k] + bias[n] ), accumulated in fp32 with

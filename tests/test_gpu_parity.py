@@ -424,7 +424,7 @@ def test_stream_kernel_k_split(ops, monkeypatch, T, ksplit):
         ys = [ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
               for _ in range(3)]
         torch.cuda.synchronize()
-        ws = ops._WORKSPACE[torch.device(DEV).index or 0]
+        ws = ops._workspace(torch.device(DEV))
         assert int(ws[:16384].view(torch.int32).abs().sum()) == 0
     finally:
         ops.drop_workspace()
@@ -451,6 +451,32 @@ def test_k_split_default_on_long_k_layers(ops):
     tol = 0.51 * 2.0 ** -7 * ref.abs() + 1e-4 * rms
     assert ((y.float() - ref).abs() <= tol).all()
 
+
+@pytest.mark.parametrize("T", [16, 128])
+def test_k_split_many_rows_long_k(ops, T):
+    """8192 rows x 14336 inputs: at 128 tokens the preferred split's partial sums (16 MiB) exceed the fixed
+    workspace, so the launch takes the largest split that fits; the workspace is the same buffer at every batch
+    size (never replaced), and its counters are zero again afterwards."""
+    parts, Kin = [8192], 14336
+    p = Problem(5 + T, 256, 8, 1, parts, Kin, T, "bf16").to(DEV)
+    assert ops.workspace_bytes(T, p.N, p.G, 1, 256, 8, 1, torch.bfloat16) > 0
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    dev = torch.device(DEV)
+    ops.ensure_workspace(dev)
+    try:
+        ws = ops._workspace(dev)
+        y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)
+        ops.ensure_workspace(dev, ops.workspace_bytes(128, p.N, p.G, 1, 256, 8, 1, torch.bfloat16))
+        assert ops._workspace(dev) is ws
+        y_again = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)
+        torch.cuda.synchronize()
+        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0
+    finally:
+        ops.drop_workspace()
+    assert torch.equal(y, y_again)
+    ref, rms = _device_reference(ops, p, parts)
+    tol = 0.51 * 2.0 ** -7 * ref.abs() + 1e-4 * rms
+    assert ((y.float() - ref).abs() <= tol).all()
 
 
 @pytest.mark.parametrize("fmt", [(256, 8, 1), (256, 4, 1), (16, 2, 1), (4096, 8, 1), (4096, 4, 1), (256, 8, 2)])

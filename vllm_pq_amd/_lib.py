@@ -18,7 +18,7 @@ PQ_DTYPE_FP16, PQ_DTYPE_BF16 = 0, 1
 EXPORTS = ("pq_version", "pq_caps", "pq_last_error", "pq_dequant", "pq_gemm_workspace_bytes", "pq_gemm",
            "pq_packed_codes_bytes", "pq_repack_codes", "pq_gemm_packed", "pq_gemm_kernel_name", "pq_silu_and_mul",
            "pq_rms_norm", "pq_fused_add_rms_norm", "pq_gemm_silu_mul_is_fused", "pq_gemm_packed_silu_mul", "pq_embedding",
-           "pq_debug_reload_knobs")
+           "pq_debug_reload_knobs", "pq_gemm_workspace_max_bytes")
 
 _lock = threading.Lock()
 _lib = None
@@ -61,6 +61,8 @@ def load():
         L.pq_embedding.restype = ctypes.c_int
         L.pq_gemm_workspace_bytes.argtypes = [i32] * 8
         L.pq_gemm_workspace_bytes.restype = sz
+        L.pq_gemm_workspace_max_bytes.argtypes = []
+        L.pq_gemm_workspace_max_bytes.restype = sz
         L.pq_gemm.argtypes = [vp, i32, i64, vp, vp, vp, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64,
                               vp, sz, vp]
         L.pq_gemm.restype = ctypes.c_int

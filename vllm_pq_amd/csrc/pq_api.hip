@@ -173,6 +173,8 @@ size_t pq_gemm_workspace_bytes(int32_t T, int32_t N, int32_t G, int32_t M, int32
     return pq::stream_workspace_bytes(T, N, G, M, K, d, code_bytes);
 }
 
+size_t pq_gemm_workspace_max_bytes(void) { return pq::WS_COUNTER_BYTES + pq::WS_PARTIAL_BYTES; }
+
 static int fill_gemm(pq::GemmArgs &a, const char *fn, const void *x, int32_t T, int64_t x_row_stride,
                      const void *codes, const void *codebooks, const void *scales, const void *bias,
                      const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K,

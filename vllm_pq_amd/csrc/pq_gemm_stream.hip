@@ -125,8 +125,9 @@ size_t stream_workspace_bytes(int T, int N, int G, int M, int K, int d, int code
     int forced;
     const int s = ksplit_limit(T, G, M, code_bytes, &forced);
     if (s == 1) return 0;
+    // beyond the cap a launch takes the largest split whose partial sums still fit
     const size_t part = (size_t)s * T * N * 4;
-    return part > WS_PARTIAL_BYTES ? 0 : WS_COUNTER_BYTES + part;
+    return WS_COUNTER_BYTES + (part > WS_PARTIAL_BYTES ? WS_PARTIAL_BYTES : part);
 }
 
 StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {

@@ -66,10 +66,13 @@ def _raise(rc: int):
 
 
 # ---- workspace of the K-split launches ---------------------------------------------------------
-# One zero-initialised buffer per device, created at weight-load time (never inside an op, so never
-# under HIP-graph capture) and shared by every layer: launches on one stream run one after the
-# other, and a launch leaves the counters at its head zero again.  Launches issued concurrently on
-# several streams of one device must not share it: call drop_workspace() to run without.
+# Zero-initialised buffers of ONE fixed size (the library's maximum, pq_gemm_workspace_max_bytes()), so that a
+# buffer is never grown and thereby replaced: launches captured into a HIP graph keep pointing to it.  One buffer
+# per (device, stream): launches on one stream run one after the other and each leaves the counters at the head
+# zero again, launches on different streams may overlap and must not share.  A stream's buffer is created at
+# weight-load time (ensure_workspace) or by the stream's first eager call.  Launches issued under graph capture use
+# the device's one capture buffer, created at load time only (nothing is allocated under capture; without it they
+# run unsplit): replays of different captured graphs must not overlap on one device.
 _WORKSPACE = {}
 
 
@@ -78,22 +81,48 @@ def workspace_bytes(T: int, N: int, G: int, M: int, K: int, d: int, code_bytes: 
     return int(_lib.load().pq_gemm_workspace_bytes(T, N, G, M, K, d, code_bytes, _DTYPE[dtype]))
 
 
-def ensure_workspace(device: torch.device, nbytes: int) -> None:
-    """Make the device's workspace at least `nbytes` large.  Call at load time, outside graph capture."""
-    if nbytes <= 0:
+def _new_workspace(idx: int) -> torch.Tensor:
+    return torch.zeros(int(_lib.load().pq_gemm_workspace_max_bytes()), dtype=torch.uint8, device=torch.device("cuda", idx))
+
+
+def ensure_workspace(device: torch.device, nbytes: Optional[int] = None) -> None:
+    """Create the workspaces of `device` for the current stream and for graph capture, if they do not exist yet.
+    Call at load time, outside graph capture.  `nbytes` (a pq_gemm_workspace_bytes value) only says whether any
+    is needed: 0 does nothing; the buffers always have the fixed maximum size."""
+    if nbytes is not None and nbytes <= 0:
         return
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
-    cur = _WORKSPACE.get(idx)
-    if cur is None or cur.numel() < nbytes:
-        _WORKSPACE[idx] = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
+    for key in ((idx, torch.cuda.current_stream(idx).cuda_stream), (idx, "graph")):
+        if key not in _WORKSPACE:
+            _WORKSPACE[key] = _new_workspace(idx)
+
+
+def _workspace(dev: torch.device) -> Optional[torch.Tensor]:
+    """The buffer a launch on the current stream of `dev` may use (None: run unsplit)."""
+    if not _WORKSPACE:
+        return None
+    idx = dev.index
+    if torch.cuda.is_current_stream_capturing():
+        return _WORKSPACE.get((idx, "graph"))
+    if (idx, "graph") not in _WORKSPACE:      # the device never asked for workspaces (or dropped them)
+        return None
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    ws = _WORKSPACE.get(key)
+    if ws is None:
+        ws = _WORKSPACE[key] = _new_workspace(idx)
+    return ws
 
 
 def drop_workspace(device: Optional[torch.device] = None) -> None:
+    """Forget the workspaces (of one device): later launches run unsplit until ensure_workspace is called again.
+    Not while a captured graph that used them may still be replayed."""
     if device is None:
         _WORKSPACE.clear()
     else:
-        _WORKSPACE.pop(torch.device(device).index, None)
+        idx = torch.device(device).index
+        for key in [k for k in _WORKSPACE if k[0] == idx]:
+            del _WORKSPACE[key]
 
 
 # ---- eager implementations ------------------------------------------------------------------
@@ -169,8 +198,8 @@ def _pq_gemm_impl(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Ten
         bias = bias.contiguous()
     out = torch.empty((T, N), dtype=input.dtype, device=dev)
     if T and N:
-        ws = _WORKSPACE.get(dev.index)
         with torch.cuda.device(dev):
+            ws = _workspace(dev)
             fn = L.pq_gemm if packed_codes is None else L.pq_gemm_packed
             cptr = codes.data_ptr() if packed_codes is None else packed_codes.data_ptr()
             rc = fn(x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, cptr,
@@ -315,8 +344,8 @@ def _pq_gemm_packed_silu_mul_impl(input: torch.Tensor, packed_codes: torch.Tenso
         cb = _CODE_BYTES[codes.dtype]
         fused = L.pq_gemm_silu_mul_is_fused(T, I, G, K, d, cb, _DTYPE[input.dtype])
         tmp = None if fused else torch.empty((T, N), dtype=input.dtype, device=dev)
-        ws = _WORKSPACE.get(dev.index)
         with torch.cuda.device(dev):
+            ws = _workspace(dev)
             rc = L.pq_gemm_packed_silu_mul(
                 x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, packed_codes.data_ptr(),
                 codebooks.contiguous().data_ptr(), scales.contiguous().data_ptr(),

@@ -182,13 +182,11 @@ class PQLinearMethod(LinearMethodBase):
                 64, N, G, M, K, d, layer.codes.element_size(), layer.codebooks.dtype, parts or [N],
                 packed=layer.pq_packed_codes is not None) == "generic"
             if layer.pq_packed_codes is not None:
-                # scratch for the K-split launches (long-K layers, up to 128 tokens): one buffer per device,
-                # sized here, at load time, for the largest batch those launches take
-                N, G, M = layer.codes.shape
-                K, d = layer.codebooks.shape[1], layer.codebooks.shape[3]
-                ops.ensure_workspace(layer.codes.device,
-                                     ops.workspace_bytes(128, N, G, M, K, d, layer.codes.element_size(),
-                                                         layer.codebooks.dtype))
+                # scratch for the K-split launches (long-K layers, up to 128 tokens): fixed-size buffers per
+                # device, created here, at load time, when a layer can use them at any batch size
+                if any(ops.workspace_bytes(T, N, G, M, K, d, layer.codes.element_size(), layer.codebooks.dtype)
+                       for T in (16, 128)):
+                    ops.ensure_workspace(layer.codes.device)
 
     def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         codebooks = layer.codebooks
