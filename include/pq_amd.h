@@ -166,6 +166,23 @@ int pq_gemm_packed(const void *x, int32_t T, int64_t x_row_stride, const void *p
                    size_t workspace_bytes, void *stream);
 
 /*
+ * pq_gemm_packed for callers that cannot allocate device memory or bring a workspace (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc): the K-split scratch is a buffer inside the
+ * library's own image, 8 MiB + 16 KiB on every GPU the library runs on, held until the process ends.  The call
+ * allocates and frees nothing.  Same arguments and results as pq_gemm_packed given a zeroed workspace of
+ * pq_gemm_workspace_max_bytes(), except that a problem whose preferred K split needs more scratch than the buffer
+ * holds (long K, more than 4096 rows and about 64 tokens or more) is rejected with PQ_ERR_WORKSPACE instead of run
+ * on a smaller split.  All calls on one GPU share that GPU's buffer: calls that may overlap there (different
+ * streams, different threads) race -- serialise them or use pq_gemm_packed with a workspace per stream.  The first
+ * call on a device looks the buffer's address up (no allocation; do it once outside graph capture).
+ * No counterpart in the reference: it is for callers that cannot allocate.
+ */
+int pq_gemm_packed_noalloc(const void *x, int32_t T, int64_t x_row_stride, const void *packed_codes,
+                           const void *codebooks, const void *scales, const void *bias /* nullable */,
+                           const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K,
+                           int32_t d, int32_t code_bytes, int32_t dtype, void *y, int64_t y_row_stride, void *stream);
+
+/*
  * Which kernel pq_gemm (packed = 0) or pq_gemm_packed (packed = 1) would run for this problem: writes a short name ("mfma_stream", "mfma_tiled",
  * "generic") into buf.  For tests, benchmarks and profiles.  No reference counterpart.
  */

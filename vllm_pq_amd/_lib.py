@@ -18,7 +18,7 @@ PQ_DTYPE_FP16, PQ_DTYPE_BF16 = 0, 1
 EXPORTS = ("pq_version", "pq_caps", "pq_last_error", "pq_dequant", "pq_gemm_workspace_bytes", "pq_gemm",
            "pq_packed_codes_bytes", "pq_repack_codes", "pq_gemm_packed", "pq_gemm_kernel_name", "pq_silu_and_mul",
            "pq_rms_norm", "pq_fused_add_rms_norm", "pq_gemm_silu_mul_is_fused", "pq_gemm_packed_silu_mul", "pq_embedding",
-           "pq_debug_reload_knobs", "pq_gemm_workspace_max_bytes")
+           "pq_debug_reload_knobs", "pq_gemm_workspace_max_bytes", "pq_gemm_packed_noalloc")
 
 _lock = threading.Lock()
 _lib = None
@@ -68,6 +68,8 @@ def load():
         L.pq_gemm.restype = ctypes.c_int
         L.pq_gemm_packed.argtypes = L.pq_gemm.argtypes
         L.pq_gemm_packed.restype = ctypes.c_int
+        L.pq_gemm_packed_noalloc.argtypes = L.pq_gemm.argtypes[:18] + [vp]
+        L.pq_gemm_packed_noalloc.restype = ctypes.c_int
         L.pq_packed_codes_bytes.argtypes = [pi32, i32, i32, i32, i32, i32, i32, i32]
         L.pq_packed_codes_bytes.restype = sz
         L.pq_repack_codes.argtypes = [vp, pi32, i32, i32, i32, i32, i32, i32, i32, vp, vp]

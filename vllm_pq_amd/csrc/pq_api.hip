@@ -2,6 +2,7 @@
 // error reporting.  No allocation, no synchronisation, no global mutable state besides the
 // thread-local error text.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -197,7 +198,7 @@ static int run_gemm(const char *fn, bool packed, const void *x, int32_t T, int64
                     const void *codebooks, const void *scales, const void *bias, const int32_t *part_sizes,
                     int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes,
                     int32_t dtype, void *y, int64_t y_row_stride, void *workspace, size_t workspace_bytes,
-                    void *stream) {
+                    void *stream, bool clear_counters = false) {
     pq::GemmArgs a;
     int rc = fill_gemm(a, fn, x, T, x_row_stride, codes, codebooks, scales, bias, part_sizes, num_parts, N, G, M, K,
                        d, code_bytes, dtype, y, y_row_stride);
@@ -216,6 +217,11 @@ static int run_gemm(const char *fn, bool packed, const void *x, int32_t T, int64
                     "%s: x, codebooks and packed_codes must be 16-byte aligned and x_row_stride a multiple of 8", fn);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e;
+    if (clear_counters && k == K_STREAM && pq::choose_stream_cfg(a, nullptr).ksplit > 1) {
+        // a workspace other calls have used: the arrival counters at its head start this launch at zero
+        e = hipMemsetAsync(workspace, 0, pq::WS_COUNTER_BYTES, s);
+        if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "%s: clearing the scratch counters: %s", fn, hipGetErrorString(e));
+    }
     switch (k) {
     case K_TILED: e = pq::launch_gemm_tiled(a, s); break;
     case K_STREAM: e = pq::launch_gemm_stream(a, s); break;
@@ -240,6 +246,50 @@ int pq_gemm_packed(const void *x, int32_t T, int64_t x_row_stride, const void *p
                    int64_t y_row_stride, void *workspace, size_t workspace_bytes, void *stream) {
     return run_gemm("pq_gemm_packed", true, x, T, x_row_stride, packed_codes, codebooks, scales, bias, part_sizes,
                     num_parts, N, G, M, K, d, code_bytes, dtype, y, y_row_stride, workspace, workspace_bytes, stream);
+}
+
+// ---- pq_gemm_packed for callers that cannot allocate ----------------------------------------------------------
+// The K-split scratch lives in the library's own image, one copy per GPU.  `scratch` is only the host-side handle
+// of the symbol; the device address is asked for once per device and that address is what launches get.
+constexpr size_t SCRATCH_BYTES = pq::WS_COUNTER_BYTES + pq::WS_PARTIAL_BYTES;
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static std::atomic<void *> g_scratch_ptr[SCRATCH_MAX_DEVICES];
+
+// Device address of `scratch` on the current device (NULL and an error text on failure).
+static void *scratch_of_current_device(const char *fn) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { fail(PQ_ERR_LAUNCH, "%s: hipGetDevice: %s", fn, hipGetErrorString(e)); return nullptr; }
+    if (dev < 0 || dev >= SCRATCH_MAX_DEVICES) { fail(PQ_ERR_UNSUPPORTED, "%s: device %d (at most %d devices)", fn, dev, SCRATCH_MAX_DEVICES); return nullptr; }
+    void *ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (ptr) return ptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+        fail(PQ_ERR_LAUNCH, "%s: hipGetSymbolAddress(scratch) on device %d: %s", fn, dev, hipGetErrorString(e));
+        return nullptr;
+    }
+    g_scratch_ptr[dev].store(ptr, std::memory_order_release);   // every thread resolves the same address
+    return ptr;
+}
+
+int pq_gemm_packed_noalloc(const void *x, int32_t T, int64_t x_row_stride, const void *packed_codes,
+                           const void *codebooks, const void *scales, const void *bias, const int32_t *part_sizes,
+                           int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes,
+                           int32_t dtype, void *y, int64_t y_row_stride, void *stream) {
+    const char *fn = "pq_gemm_packed_noalloc";
+    void *ptr = nullptr;
+    if (T > 0 && N > 0 && G > 0) {
+        const size_t want = pq::stream_preferred_workspace_bytes(T, N, G, M, K, d, code_bytes);
+        if (want > SCRATCH_BYTES)
+            return fail(PQ_ERR_WORKSPACE, "%s: T=%d x N=%d with %d input groups splits K with %zu bytes of scratch, the "
+                        "built-in buffer holds %zu: use pq_gemm_packed with a workspace of the caller's, or a smaller batch",
+                        fn, T, N, G, want, SCRATCH_BYTES);
+        ptr = scratch_of_current_device(fn);
+        if (!ptr) return PQ_ERR_LAUNCH;
+    }
+    return run_gemm(fn, true, x, T, x_row_stride, packed_codes, codebooks, scales, bias, part_sizes, num_parts, N, G, M,
+                    K, d, code_bytes, dtype, y, y_row_stride, ptr, ptr ? SCRATCH_BYTES : 0, stream, true);
 }
 
 size_t pq_packed_codes_bytes(const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K,

@@ -130,6 +130,13 @@ size_t stream_workspace_bytes(int T, int N, int G, int M, int K, int d, int code
     return WS_COUNTER_BYTES + (part > WS_PARTIAL_BYTES ? WS_PARTIAL_BYTES : part);
 }
 
+size_t stream_preferred_workspace_bytes(int T, int N, int G, int M, int K, int d, int code_bytes) {
+    if (!stream_format_supported(d, K, M, code_bytes)) return 0;
+    int forced;
+    const int s = ksplit_limit(T, G, M, code_bytes, &forced);
+    return s == 1 ? 0 : WS_COUNTER_BYTES + (size_t)s * T * N * 4;
+}
+
 StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {
     const bool light = stream_light_format(a), packed = a.packed;
     if (model_us) *model_us = 0.0;

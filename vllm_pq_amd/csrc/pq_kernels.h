@@ -54,6 +54,8 @@ constexpr size_t WS_PARTIAL_BYTES = (size_t)8 << 20;
 bool stream_ksplit_ok(const GemmArgs &a, int nf, int tf, int ksplit);
 // Bytes of workspace with which this problem may run K-split (0: it never does).
 size_t stream_workspace_bytes(int T, int N, int G, int M, int K, int d, int code_bytes);
+// The same without the cap of WS_PARTIAL_BYTES: what the problem's preferred split would take.
+size_t stream_preferred_workspace_bytes(int T, int N, int G, int M, int K, int d, int code_bytes);
 StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us);
 hipError_t launch_gemm_stream(const GemmArgs &a, hipStream_t stream);
 // Fused gate/up GEMM + SiLU-and-mul on the streaming kernel: a.parts = two equal partitions (gate, up), a.y is
