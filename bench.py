@@ -93,32 +93,41 @@ def run_step(stack, inputs):
 
 
 class StepRunner:
-    """Runs the step eagerly or, when capture works, as one HIP graph replay (as vLLM does for decode)."""
+    """Runs `fn` eagerly or, when capture works, as one HIP graph replay (as vLLM does for decode).  With several
+    ranks the graph holds the RCCL all-reduces too; capture runs in thread-local error mode (the process group's
+    watchdog thread polls events meanwhile), and the ranks agree afterwards: if capture failed on any of them, all
+    of them launch eagerly, in this same process."""
 
-    def __init__(self, stack, inputs, use_graph):
-        self.stack, self.inputs, self.graph = stack, inputs, None
+    def __init__(self, fn, use_graph, dist_on=False):
+        self.fn, self.graph = fn, None
         if use_graph:
             try:
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
-                    run_step(stack, inputs)
+                    fn()
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self.out = run_step(stack, inputs)
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.out = fn()
                 self.graph = g
             except Exception as e:  # capture unsupported (e.g. a collective): fall back to eager launches
                 print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 self.graph = None
                 torch.cuda.synchronize()
+            if dist_on:
+                import torch.distributed as dist
+                ok = torch.tensor([1 if self.graph is not None else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    self.graph = None
 
     def __call__(self):
         if self.graph is not None:
             self.graph.replay()
         else:
-            run_step(self.stack, self.inputs)
+            self.fn()
 
 
 def timed_steps(runner, steps, warmup, dist_on):
@@ -267,9 +276,35 @@ def profiled_traffic(key):
     return None
 
 
-def measure(stack, T, steps, warmup, device, dtype, world, dist_on, use_graph):
+def split_times(stack, inputs, T, steps, warmup, device, dtype, dist_on, use_graph):
+    """Several ranks: where a step's time goes.  `kernel_ms` = the step with the row-parallel layers' all-reduces
+    switched off (the 128 GEMM launches alone), `allreduce_ms` = the step's 64 all-reduces alone, on [T, hidden]
+    tensors; each timed like the step itself (barrier + synchronize either side, max over ranks)."""
+    import torch.distributed as dist
+    rows = [l for b in stack for l in b.values() if getattr(l, "reduce_results", False)]
+    for l in rows:
+        l.reduce_results = False
+    try:
+        k = timed_steps(StepRunner(lambda: run_step(stack, inputs), use_graph, dist_on), steps, warmup, dist_on) / steps
+    finally:
+        for l in rows:
+            l.reduce_results = True
+    hidden = rows[0].output_size
+    bufs = [torch.zeros(T, hidden, device=device, dtype=dtype) for _ in range(4)]    # sums of zeros stay finite
+
+    def reduces():      # what tensor_model_parallel_all_reduce(out, in_place=True) issues for a row-parallel layer
+        for i in range(len(rows)):
+            if dist_on:
+                dist.all_reduce(bufs[i % 4], op=dist.ReduceOp.SUM)
+    a = timed_steps(StepRunner(reduces, use_graph, dist_on), steps, warmup, dist_on) / steps
+    return {"kernel_ms": k * 1e3, "allreduce_ms": a * 1e3, "kernel_plus_allreduce_ms": (k + a) * 1e3,
+            "allreduces_per_step": len(rows), "allreduce_bytes": T * hidden * 2,
+            "rccl_ranks": dist.get_world_size() if dist_on else 1}
+
+
+def measure(stack, T, steps, warmup, device, dtype, world, dist_on, use_graph, split=False):
     inputs = make_inputs(stack[0], T, device, dtype)
-    runner = StepRunner(stack, inputs, use_graph)
+    runner = StepRunner(lambda: run_step(stack, inputs), use_graph, dist_on)
     dt = timed_steps(runner, steps, warmup, dist_on)
     per_step = dt / steps
     # whole-job work: the unsharded model's FLOPs; bytes: what all ranks must move
@@ -277,7 +312,8 @@ def measure(stack, T, steps, warmup, device, dtype, world, dist_on, use_graph):
     byts = sum(algorithmic_bytes(T, n, kin, p) for (_, n, kin, p) in shapes_of(stack[0])) * len(stack) * world
     return dict(per_step=per_step, tflops=flops / per_step / 1e12, gbps=byts / per_step / 1e9,
                 tokens_per_s=T / per_step, launch="hipgraph" if runner.graph is not None else "eager",
-                inputs=inputs)
+                inputs=inputs,
+                split=split_times(stack, inputs, T, steps, warmup, device, dtype, dist_on, use_graph) if world > 1 or split else None)
 
 
 def main():
@@ -290,9 +326,11 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--layers", type=int, default=None, help="decoder layers (default: all 32)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
-    ap.add_argument("--graph-collectives", action="store_true",
-                    help="with --gpus > 1, also capture the steps (RCCL all-reduces included) into a HIP graph; "
-                         "by default multi-GPU steps are launched eagerly")
+    ap.add_argument("--eager-collectives", action="store_true",
+                    help="with --gpus > 1, launch the steps eagerly; by default they are captured, RCCL all-reduces "
+                         "included, into a HIP graph (falling back to eager launches when capture fails)")
+    ap.add_argument("--split-times", action="store_true",
+                    help="report kernel_ms / allreduce_ms on one GPU too (always reported with --gpus > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-neighbours", action="store_true", help="skip the element-wise kernels' measurement")
@@ -323,11 +361,11 @@ def main():
     from vllm_pq_amd import ops
     stack = build_stack(world, device, dtype, layers=args.layers)
     T = args.tokens
-    # a step with collectives is launched eagerly unless asked otherwise: the launches are asynchronous and
-    # hide behind the GPU work at the default token count, and no capture of RCCL calls can fail the run
-    use_graph = not args.no_graph and (world == 1 or args.graph_collectives)
+    # a step is one HIP graph replay, collectives included: 128 GEMM launches and 64 all-reduces issued from Python
+    # would make a decode step host-bound
+    use_graph = not args.no_graph and (world == 1 or not args.eager_collectives)
 
-    main_m = measure(stack, T, args.steps, args.warmup, device, dtype, world, dist_on, use_graph)
+    main_m = measure(stack, T, args.steps, args.warmup, device, dtype, world, dist_on, use_graph, args.split_times)
 
     # dominant kernel: gate_up_proj (largest share of FLOPs and of code bytes)
     dom = "gate_up_proj"
@@ -353,11 +391,12 @@ def main():
     decode = None
     if not args.no_decode and args.decode_tokens != T:
         Td = args.decode_tokens
-        dm = measure(stack, Td, max(args.steps, 20), args.warmup, device, dtype, world, dist_on, use_graph)
+        dm = measure(stack, Td, max(args.steps, 20), args.warmup, device, dtype, world, dist_on, use_graph, args.split_times)
         t_kd = time_dominant_kernel(stack, dm["inputs"], dom, reps)
         kb = algorithmic_bytes(Td, n_d, kin_d, p_d)
         decode = {"tokens": Td, "ms_per_step": dm["per_step"] * 1e3, "tflops": dm["tflops"], "hbm_gbps": dm["gbps"],
                   "tokens_per_s": dm["tokens_per_s"], "launch": dm["launch"],
+                  **(dm["split"] or {}),
                   "roofline": {"bound": "hbm", "achieved": kb / t_kd / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": kb / t_kd / 1e9 / HBM_PEAK_GBPS,
                                "traffic": profiled_traffic(f"{dom}@T{Td}:" + ops.gemm_kernel_name(
@@ -390,6 +429,8 @@ def main():
             "hbm_gbps": main_m["gbps"], "tokens_per_s": main_m["tokens_per_s"],
             "roofline": roof, "cpu_baseline": cpu, "decode": decode, "neighbours": neighbours,
         }
+        if main_m["split"]:
+            line.update(main_m["split"])
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()

@@ -137,6 +137,9 @@ def worker(rank, world, port, out):
         t = torch.arange(8, dtype=torch.float32) * (rank + 1)
         res["allreduce"] = ps.tensor_model_parallel_all_reduce(t)
         assert torch.equal(t, torch.arange(8, dtype=torch.float32) * (rank + 1))     # out of place
+        own = t.clone()                                                              # in place for a tensor the caller owns
+        assert ps.tensor_model_parallel_all_reduce(own, in_place=True) is own
+        res["allreduce_in_place"] = own
         torch.save(res, os.path.join(out, f"rank{rank}.pt"))
     finally:
         ps.destroy_model_parallel()
@@ -181,6 +184,7 @@ def test_two_rank_tensor_parallel_matches_unsharded(tmp_path):
         assert torch.allclose(r[rank]["down_split"].float(), down_full.float(), **tol)
         assert torch.equal(r[rank]["col_gathered"], dense(w["col"], x))
         assert torch.equal(r[rank]["allreduce"], torch.arange(8, dtype=torch.float32) * 3)
+        assert torch.equal(r[rank]["allreduce_in_place"], torch.arange(8, dtype=torch.float32) * 3)
     assert torch.equal(r[0]["down"], r[1]["down"])
 
     table = reconstruct_partition(w["vocab"]["codes"], w["vocab"]["codebooks"], w["vocab"]["scales"])

@@ -306,5 +306,5 @@ class RowParallelLinear(LinearBase):
         bias = None if (self.tp_rank > 0 or self.skip_bias_add) else self.bias
         out = self.quant_method.apply(self, x, bias=bias)
         if self.reduce_results and self.tp_size > 1:
-            out = tensor_model_parallel_all_reduce(out)
+            out = tensor_model_parallel_all_reduce(out, in_place=True)     # apply()'s output is this call's own
         return self._result(out)

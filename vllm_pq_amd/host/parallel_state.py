@@ -45,11 +45,13 @@ def get_tensor_model_parallel_world_size() -> int:
     return _TP_SIZE
 
 
-def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
-    """Out-of-place SUM over the TP group (RowParallelLinear.forward, linear.py:1212-1213)."""
+def tensor_model_parallel_all_reduce(input_: torch.Tensor, in_place: bool = False) -> torch.Tensor:
+    """SUM over the TP group (RowParallelLinear.forward, linear.py:1212-1213).  Out of place by default, as the
+    reference's op is for its callers; `in_place=True` reduces into `input_` itself and returns it -- for a caller
+    that owns the tensor (the row-parallel layer: its GEMM output is fresh), which saves a copy per call."""
     if _TP_SIZE == 1:
         return input_
-    out = input_.clone()
+    out = input_ if in_place and input_.is_contiguous() else input_.clone(memory_format=torch.contiguous_format)
     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=_TP_GROUP)
     return out
 
