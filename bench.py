@@ -181,9 +181,26 @@ def time_dominant_kernel(stack, inputs, name, reps):
     return sorted(per_launch)[len(per_launch) // 2]
 
 
-def cpu_baseline(T, dtype, budget_s=12.0, cap_s=30.0):
-    """The reference's CPU algorithm (torch-CPU restatement) on one decoder layer's four linears,
-    repeated until about `budget_s` seconds of CPU work have been timed."""
+def host_cpu():
+    """Model string and the vector ISA levels of the host CPU (what the torch-CPU operators can use)."""
+    model, flags = "unknown", set()
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("flags") and not flags:
+                    flags = set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    isa = [k for k in ("avx2", "avx512f", "avx512_bf16", "avx512_fp16", "amx_bf16", "amx_tile") if k in flags]
+    return model, isa
+
+
+def cpu_baseline(T, dtype, budget_s=12.0, min_calls=5):
+    """The reference's CPU algorithm (torch-CPU restatement) on one decoder layer's four linears at T tokens: every
+    linear is called at least `min_calls` times (and until its share of about `budget_s` seconds is used), the
+    rate is the layer's FLOPs over the sum of the four MEDIAN call times."""
     from oracle.torch_restatement import pq_linear_cpu
     cfg = LLAMA3_8B
     q, kv = cfg["heads"] * cfg["head_dim"], cfg["kv_heads"] * cfg["head_dim"]
@@ -191,32 +208,32 @@ def cpu_baseline(T, dtype, budget_s=12.0, cap_s=30.0):
            ("gate_up_proj", [cfg["inter"]] * 2, cfg["hidden"]), ("down_proj", [cfg["hidden"]], cfg["inter"])]
     g = torch.Generator().manual_seed(99)
     cores = torch.get_num_threads()
-    data = []
-    for name, parts, kin in lin:
+    flops, med_secs, calls, spent = 0.0, 0.0, 0, 0.0
+    for i, (name, parts, kin) in enumerate(lin):
         n = sum(parts)
-        data.append((name, parts, kin, n,
-                     torch.randint(-128, 128, (n, kin // SUB_DIM, 1), generator=g, dtype=torch.int8),
-                     torch.randn(len(parts), K_ENTRIES, 1, SUB_DIM, generator=g).to(dtype),
-                     (torch.rand(n, 1, 1, 1, generator=g) + 0.5).to(dtype),
-                     torch.randn(T, kin, generator=g).to(dtype)))
-    d0 = data[1]
-    pq_linear_cpu(d0[7][:8], d0[4], d0[5], d0[6], d0[1], None)      # warm the operators up
-    flops, secs, calls = 0.0, 0.0, 0
-    while secs < budget_s:
-        for name, parts, kin, n, codes, cb, sc, x in data:
+        codes = torch.randint(-128, 128, (n, kin // SUB_DIM, 1), generator=g, dtype=torch.int8)
+        cb = torch.randn(len(parts), K_ENTRIES, 1, SUB_DIM, generator=g).to(dtype)
+        sc = (torch.rand(n, 1, 1, 1, generator=g) + 0.5).to(dtype)
+        x = torch.randn(T, kin, generator=g).to(dtype)
+        if i == 0:
+            pq_linear_cpu(x[:8], codes[:256], cb[:1], sc[:256], [256], None)      # warm the operators up
+        share = budget_s * (n * kin) / sum(sum(p_) * k_ for _, p_, k_ in lin)
+        times = []
+        while len(times) < min_calls or (sum(times) < share and len(times) < 200):
             t0 = time.perf_counter()
             pq_linear_cpu(x, codes, cb, sc, parts, None)
-            secs += time.perf_counter() - t0
-            flops += 2.0 * T * n * kin
-            calls += 1
-            if secs > cap_s:
-                break
-        if secs > cap_s:
-            break
-    return {"value": flops / secs / 1e12, "unit": "TFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"{calls} apply() calls cycling qkv/o/gate_up/down of one Llama-3-8B decoder layer at T={T} "
-                      f"({secs:.1f} s of CPU work, {cores} threads), torch-CPU restatement of the reference's "
-                      f"generic_dequantize_gemm"}
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        med_secs += times[len(times) // 2]
+        spent += sum(times)
+        calls += len(times)
+        flops += 2.0 * T * n * kin
+    model, isa = host_cpu()
+    return {"value": flops / med_secs / 1e12, "unit": "TFLOP/s", "cores": cores, "kind": "port",
+            "cpu_model": model, "cpu_isa": isa, "tokens": T, "layer_ms": med_secs * 1e3,
+            "sample": f"{calls} apply() calls over qkv/o/gate_up/down of one Llama-3-8B decoder layer at T={T} "
+                      f"(at least {min_calls} per linear, median call time of each; {spent:.1f} s of CPU work, "
+                      f"{cores} threads), torch-CPU restatement of the reference's generic_dequantize_gemm"}
 
 
 def time_neighbours(T, device, dtype, world, cfg=LLAMA3_8B, reps=5):
@@ -415,6 +432,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(T, dtype)
+        if decode is not None:      # the decode regime: the same algorithm re-dequantises the weights for 16 tokens
+            decode["cpu_baseline"] = cpu_baseline(args.decode_tokens, dtype, budget_s=8.0)
 
     if rank == 0:
         line = {
