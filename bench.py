@@ -84,6 +84,55 @@ def make_inputs(block, T, device, dtype):
             for name, layer in block.items()}
 
 
+# ---- launch log (profiling aid) -------------------------------------------------------------------------
+# With --launch-log every PQ GEMM launch of the process is recorded in launch order as (layer, T, N, Kin, kernel);
+# a graph replay appends what its capture recorded.  tools/proftrace.py aligns the list with the GEMM dispatches of a
+# rocprofv3 kernel trace of the same run, so durations are keyed by problem rather than by (kernel, grid) -- the
+# persistent tiled kernel launches 256 blocks whatever the layer.
+LAUNCH_LOG = None
+
+
+def enable_launch_log(stack, dtype):
+    global LAUNCH_LOG
+    from vllm_pq_amd import ops
+    from vllm_pq_amd.pq import PQLinearMethod
+    LAUNCH_LOG = []
+    names = {}
+    for name, layer in stack[0].items():
+        names[(layer.codes.shape[0], layer.codes.shape[1])] = name
+    plain = PQLinearMethod.apply
+
+    def logged(self, layer, x, bias=None):
+        N, G, M = layer.codes.shape
+        T = x.numel() // x.shape[-1]
+        parts = getattr(layer.codebooks, "output_partition_sizes", [])
+        kern = ops.gemm_kernel_name(T, N, G, M, layer.codebooks.shape[1], layer.codebooks.shape[3],
+                                    layer.codes.element_size(), dtype, parts,
+                                    packed=getattr(layer, "pq_packed_codes", None) is not None)
+        LAUNCH_LOG.append([names.get((N, G), "?"), T, N, G * layer.codebooks.shape[3], kern])
+        return plain(self, layer, x, bias)
+
+    PQLinearMethod.apply = logged
+
+
+class Graph:
+    """torch.cuda.CUDAGraph whose replays also replay the launch log of its capture."""
+
+    def __init__(self, fn, **capture_args):
+        self.g = torch.cuda.CUDAGraph()
+        n0 = len(LAUNCH_LOG) if LAUNCH_LOG is not None else 0
+        with torch.cuda.graph(self.g, **capture_args):
+            self.out = fn()
+        self.logged = LAUNCH_LOG[n0:] if LAUNCH_LOG is not None else []
+        if LAUNCH_LOG is not None:
+            del LAUNCH_LOG[n0:]            # capture launches nothing
+
+    def replay(self):
+        self.g.replay()
+        if LAUNCH_LOG is not None:
+            LAUNCH_LOG.extend(self.logged)
+
+
 def run_step(stack, inputs):
     out = None
     for block in stack:
@@ -108,10 +157,7 @@ class StepRunner:
                     fn()
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self.out = fn()
-                self.graph = g
+                self.graph = Graph(fn, capture_error_mode="thread_local")
             except Exception as e:  # capture unsupported (e.g. a collective): fall back to eager launches
                 print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 self.graph = None
@@ -165,10 +211,10 @@ def time_dominant_kernel(stack, inputs, name, reps):
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):        # graph replay: back-to-back launches without host gaps
+    def launches():
         for i in range(reps):
             qm.apply(layers[i % len(layers)], x)
+    g = Graph(launches)              # graph replay: back-to-back launches without host gaps
     g.replay()
     torch.cuda.synchronize()
     per_launch = []
@@ -348,6 +394,8 @@ def main():
                          "included, into a HIP graph (falling back to eager launches when capture fails)")
     ap.add_argument("--split-times", action="store_true",
                     help="report kernel_ms / allreduce_ms on one GPU too (always reported with --gpus > 1)")
+    ap.add_argument("--launch-log", default=None,
+                    help="write the process's PQ GEMM launches, in launch order, to this JSON file (for tools/proftrace.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-neighbours", action="store_true", help="skip the element-wise kernels' measurement")
@@ -378,6 +426,8 @@ def main():
     from vllm_pq_amd import ops
     stack = build_stack(world, device, dtype, layers=args.layers)
     T = args.tokens
+    if args.launch_log:
+        enable_launch_log(stack, dtype)
     # a step is one HIP graph replay, collectives included: 128 GEMM launches and 64 all-reduces issued from Python
     # would make a decode step host-bound
     use_graph = not args.no_graph and (world == 1 or not args.eager_collectives)
@@ -451,6 +501,9 @@ def main():
         if main_m["split"]:
             line.update(main_m["split"])
         print(json.dumps(line), flush=True)
+        if args.launch_log:
+            with open(args.launch_log, "w") as f:
+                json.dump(LAUNCH_LOG, f)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
