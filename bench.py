@@ -355,14 +355,19 @@ def split_times(stack, inputs, T, steps, warmup, device, dtype, dist_on, use_gra
     hidden = rows[0].output_size
     bufs = [torch.zeros(T, hidden, device=device, dtype=dtype) for _ in range(4)]    # sums of zeros stay finite
 
-    def reduces():      # what tensor_model_parallel_all_reduce(out, in_place=True) issues for a row-parallel layer
+    from vllm_pq_amd.host import parallel_state
+
+    def reduces():      # what a row-parallel layer issues behind its GEMM
         for i in range(len(rows)):
-            if dist_on:
+            if parallel_state.get_tensor_model_parallel_world_size() > 1:
+                parallel_state.tensor_model_parallel_all_reduce(bufs[i % 4], in_place=True)
+            elif dist_on:   # one-rank rehearsal of the distributed path: the collective itself
                 dist.all_reduce(bufs[i % 4], op=dist.ReduceOp.SUM)
     a = timed_steps(StepRunner(reduces, use_graph, dist_on), steps, warmup, dist_on) / steps
     return {"kernel_ms": k * 1e3, "allreduce_ms": a * 1e3, "kernel_plus_allreduce_ms": (k + a) * 1e3,
             "allreduces_per_step": len(rows), "allreduce_bytes": T * hidden * 2,
-            "rccl_ranks": dist.get_world_size() if dist_on else 1}
+            "rccl_ranks": dist.get_world_size() if dist_on else 1,
+            "small_allreduce": "xgmi-peer-buffers" if parallel_state._XGMI_AR is not None else "rccl"}
 
 
 def measure(stack, T, steps, warmup, device, dtype, world, dist_on, use_graph, split=False):
@@ -392,6 +397,9 @@ def main():
     ap.add_argument("--eager-collectives", action="store_true",
                     help="with --gpus > 1, launch the steps eagerly; by default they are captured, RCCL all-reduces "
                          "included, into a HIP graph (falling back to eager launches when capture fails)")
+    ap.add_argument("--xgmi-allreduce", action="store_true",
+                    help="with --gpus > 1, sum messages of up to 2 MiB with the library's peer-buffer all-reduce "
+                         "instead of RCCL (not yet measured on multi-GPU hardware: off by default)")
     ap.add_argument("--split-times", action="store_true",
                     help="report kernel_ms / allreduce_ms on one GPU too (always reported with --gpus > 1)")
     ap.add_argument("--launch-log", default=None,
@@ -422,6 +430,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         parallel_state.initialize_model_parallel(world)
+        if args.xgmi_allreduce and world > 1:
+            parallel_state.enable_xgmi_all_reduce()
 
     from vllm_pq_amd import ops
     stack = build_stack(world, device, dtype, layers=args.layers)

@@ -233,6 +233,44 @@ int pq_gemm_packed_silu_mul(const void *x, int32_t T, int64_t x_row_stride, cons
                             int64_t y_row_stride, void *tmp /* nullable */, void *workspace, size_t workspace_bytes,
                             void *stream);
 
+/*
+ * Small-message all-reduce (SUM) between the tensor-parallel ranks of one node, one process per GPU, over device
+ * buffers the ranks map into each other (IPC handles; xGMI carries the loads and stores): the sum a row-parallel
+ * PQ linear needs behind its GEMM (vllm/model_executor/layers/linear.py:1206-1213) at decode batch sizes.  It
+ * replaces the reference's custom all-reduce for this path (csrc/custom_all_reduce.cuh:214-280 the one- and
+ * two-stage kernels, :478-491 their dispatch by message size; host side
+ * vllm/distributed/device_communicators/custom_all_reduce.py), with RCCL remaining the path for larger messages.
+ *
+ *   pq_ar_alloc      this rank's communication buffer (pq_ar_buffer_bytes() of uncached device memory, zeroed) and
+ *                    its 64-byte IPC handle, which the host sends to the other ranks (any side channel)
+ *   pq_ar_open       maps another rank's buffer from its handle; pq_ar_close / pq_ar_free undo the two
+ *   pq_ar_create     a communicator from the `world` buffer addresses as seen by THIS process
+ *                    (buffers[rank] = the own one), 2 to 8 ranks; pq_ar_destroy frees it (not the buffers)
+ *   pq_ar_all_reduce out[i] = sum over ranks of in[i], i < count, dtype PQ_DTYPE_FP16 / PQ_DTYPE_BF16 or 2 = fp32;
+ *                    fp32 accumulation in rank order, so every rank gets the same bits.  in == out is allowed.
+ *                    The message must be a multiple of 16 bytes, 16-byte aligned, at most
+ *                    pq_ar_max_message_bytes() (2 MiB); one shot up to 256 KiB, reduce-scatter + all-gather above.
+ *                    Every rank must issue the same sequence of calls (count, dtype).  Enqueues one kernel on
+ *                    `stream`; no allocation, no host synchronisation: capturable into a HIP graph.
+ *   pq_ar_status     synchronous check after the stream has been synchronised: non-zero when a wait for a peer's
+ *                    flag gave up (2 s), after which the communicator must not be used any more
+ * These calls are the only ones in the library that allocate (pq_ar_alloc) or keep pointers (the communicator).
+ * Return 0 or a pq_status code; pq_ar_last_error() has the text.
+ */
+#define PQ_AR_MAX_RANKS 8
+#define PQ_AR_IPC_HANDLE_BYTES 64
+const char *pq_ar_last_error(void);
+size_t pq_ar_buffer_bytes(void);
+size_t pq_ar_max_message_bytes(void);
+int pq_ar_alloc(void **buffer, void *ipc_handle /* out: PQ_AR_IPC_HANDLE_BYTES */);
+int pq_ar_free(void *buffer);
+int pq_ar_open(const void *ipc_handle, void **peer_buffer);
+int pq_ar_close(void *peer_buffer);
+int pq_ar_create(int32_t rank, int32_t world, void *const *buffers, void **comm);
+int pq_ar_destroy(void *comm);
+int pq_ar_all_reduce(void *comm, const void *in, void *out, int64_t count, int32_t dtype, void *stream);
+int pq_ar_status(void *comm);
+
 #ifdef __cplusplus
 }
 #endif

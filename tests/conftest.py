@@ -14,6 +14,43 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# The two ranks of tests/test_xgmi_all_reduce.py: fresh processes started here, before this process has touched the
+# GPU (a process that has initialised the GPU must not start programs that use it by fork + exec).
+XGMI_JOB = None
+
+
+def pytest_sessionstart(session):
+    global XGMI_JOB
+    expr = session.config.getoption("markexpr", "") or ""
+    if "gpu" not in expr or "not gpu" in expr:
+        return
+    import socket
+    import subprocess
+    import tempfile
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:        # counting devices does not initialise the GPU
+            return
+    except Exception:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tempfile.mkdtemp(prefix="pq_xgmi_")
+    world = 2
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "xgmi_worker.py"), str(r), str(world),
+                               str(port), out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+             for r in range(world)]
+    XGMI_JOB = {"procs": procs, "dir": out, "world": world}
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if XGMI_JOB is not None:
+        for p in XGMI_JOB["procs"]:
+            if p.poll() is None:
+                p.kill()
+
+
 class Golden:
     """Golden vectors produced by the reference's own Python (tests/golden/make_golden.py)."""
 

@@ -18,7 +18,9 @@ PQ_DTYPE_FP16, PQ_DTYPE_BF16 = 0, 1
 EXPORTS = ("pq_version", "pq_caps", "pq_last_error", "pq_dequant", "pq_gemm_workspace_bytes", "pq_gemm",
            "pq_packed_codes_bytes", "pq_repack_codes", "pq_gemm_packed", "pq_gemm_kernel_name", "pq_silu_and_mul",
            "pq_rms_norm", "pq_fused_add_rms_norm", "pq_gemm_silu_mul_is_fused", "pq_gemm_packed_silu_mul", "pq_embedding",
-           "pq_debug_reload_knobs", "pq_gemm_workspace_max_bytes", "pq_gemm_packed_noalloc")
+           "pq_debug_reload_knobs", "pq_gemm_workspace_max_bytes", "pq_gemm_packed_noalloc", "pq_ar_last_error", "pq_ar_buffer_bytes",
+           "pq_ar_max_message_bytes", "pq_ar_alloc", "pq_ar_free", "pq_ar_open", "pq_ar_close", "pq_ar_create",
+           "pq_ar_destroy", "pq_ar_all_reduce", "pq_ar_status")
 
 _lock = threading.Lock()
 _lib = None
@@ -90,6 +92,24 @@ def load():
         L.pq_gemm_packed_silu_mul.restype = ctypes.c_int
         L.pq_debug_reload_knobs.argtypes = []
         L.pq_debug_reload_knobs.restype = None
+        pvp = ctypes.POINTER(vp)
+        L.pq_ar_last_error.argtypes = []
+        L.pq_ar_last_error.restype = ctypes.c_char_p
+        L.pq_ar_buffer_bytes.argtypes = []
+        L.pq_ar_buffer_bytes.restype = sz
+        L.pq_ar_max_message_bytes.argtypes = []
+        L.pq_ar_max_message_bytes.restype = sz
+        L.pq_ar_alloc.argtypes = [pvp, ctypes.c_char_p]
+        L.pq_ar_free.argtypes = [vp]
+        L.pq_ar_open.argtypes = [ctypes.c_char_p, pvp]
+        L.pq_ar_close.argtypes = [vp]
+        L.pq_ar_create.argtypes = [i32, i32, pvp, pvp]
+        L.pq_ar_destroy.argtypes = [vp]
+        L.pq_ar_all_reduce.argtypes = [vp, vp, vp, i64, i32, vp]
+        L.pq_ar_status.argtypes = [vp]
+        for fn in ("pq_ar_alloc", "pq_ar_free", "pq_ar_open", "pq_ar_close", "pq_ar_create", "pq_ar_destroy",
+                   "pq_ar_all_reduce", "pq_ar_status"):
+            getattr(L, fn).restype = ctypes.c_int
         if L.pq_version() != PQ_ABI_VERSION:
             raise PQLibraryError(f"{LIB_PATH}: ABI version {L.pq_version()} != {PQ_ABI_VERSION}")
         _lib = L

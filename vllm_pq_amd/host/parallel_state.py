@@ -14,6 +14,7 @@ import torch.distributed as dist
 _TP_GROUP: Optional["dist.ProcessGroup"] = None
 _TP_RANK = 0
 _TP_SIZE = 1
+_XGMI_AR = None          # XgmiAllReduce of the TP group, when enabled
 
 
 def initialize_model_parallel(tensor_model_parallel_size: Optional[int] = None,
@@ -32,8 +33,29 @@ def initialize_model_parallel(tensor_model_parallel_size: Optional[int] = None,
     _TP_GROUP, _TP_RANK, _TP_SIZE = g, dist.get_rank(g), size
 
 
+def enable_xgmi_all_reduce(max_bytes: Optional[int] = None) -> bool:
+    """Collective over the TP group (2 to 8 GPUs of one node): from now on tensor_model_parallel_all_reduce sums
+    small contiguous fp16 / bf16 / fp32 GPU tensors with the library's peer-buffer all-reduce (one launch, no
+    ring) and everything else with RCCL, as the reference's communicator prefers its custom all-reduce by size
+    (vllm/distributed/device_communicators/custom_all_reduce.py should_custom_ar).  False when not applicable."""
+    global _XGMI_AR
+    if _TP_SIZE < 2 or _TP_SIZE > 8 or not torch.cuda.is_available():
+        return False
+    from .xgmi_all_reduce import XgmiAllReduce
+    _XGMI_AR = XgmiAllReduce(_TP_GROUP, max_bytes)
+    return True
+
+
+def disable_xgmi_all_reduce() -> None:
+    global _XGMI_AR
+    if _XGMI_AR is not None:
+        _XGMI_AR.close()
+        _XGMI_AR = None
+
+
 def destroy_model_parallel() -> None:
     global _TP_GROUP, _TP_RANK, _TP_SIZE
+    disable_xgmi_all_reduce()
     _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
 
 
@@ -51,6 +73,8 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor, in_place: bool = Fals
     that owns the tensor (the row-parallel layer: its GEMM output is fresh), which saves a copy per call."""
     if _TP_SIZE == 1:
         return input_
+    if _XGMI_AR is not None and _XGMI_AR.should_use(input_):
+        return _XGMI_AR.all_reduce(input_, input_ if in_place else None)
     out = input_ if in_place and input_.is_contiguous() else input_.clone(memory_format=torch.contiguous_format)
     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=_TP_GROUP)
     return out
