@@ -402,6 +402,39 @@ def test_llama3_8b_full_size_packed_path(ops, name, parts, Kin, T):
     assert torch.equal(y2, y * 2)
 
 
+@pytest.mark.parametrize("hidden", [4096, 8192])
+@pytest.mark.parametrize("K", [16, 256, 4096])
+@pytest.mark.parametrize("d", [2, 4, 8])
+@pytest.mark.parametrize("T", [16, 256, 2048])
+def test_square_sweep_formats_full_size(ops, hidden, K, d, T):
+    """Every (codebook size, sub-vector length) of the square sweep at its full size (hidden x hidden), on the
+    kernel the dispatch picks at this T: against an fp32 matmul over the bit-exact dequantised weight on the device,
+    plus linearity in x (exact in binary floating point), the size-independent property of the path."""
+    torch.manual_seed(hidden + K + d + T)
+    N, G, parts = hidden, hidden // d, [hidden]
+    idt = torch.int8 if K <= 256 else torch.int16
+    lo, hi = (-(K // 2), K // 2) if K >= 256 else (-128, 128)      # stored values reduce mod K to valid indices
+    codes = torch.randint(lo, hi, (N, G, 1), dtype=torch.int32, device=DEV).to(idt)
+    cb = torch.randn(1, K, 1, d, device=DEV).to(torch.bfloat16)
+    scales = (torch.rand(N, 1, 1, 1, device=DEV) + 0.5).to(torch.bfloat16)
+    x = torch.randn(T, hidden, device=DEV).to(torch.bfloat16)
+    packed = ops.pq_repack_codes(codes, cb, parts)
+    assert packed is not None
+
+    def run(inp):
+        return ops.pq_gemm_packed(inp, packed, codes, cb, scales, parts, None)
+
+    y = run(x)
+    w = ops.pq_dequant(codes, cb, parts)
+    ref = (x.float() @ w.float().t()) * scales.view(1, -1).float()
+    rms = ref.pow(2).mean().sqrt()
+    tol = 0.51 * 2.0 ** -7 * ref.abs() + 1e-4 * rms
+    bad = (y.float() - ref).abs() > tol
+    kern = ops.gemm_kernel_name(T, N, G, 1, K, d, codes.element_size(), x.dtype, parts, packed=True)
+    assert not bad.any(), f"K={K} d={d} T={T} {kern}: {int(bad.sum())} of {bad.numel()} outside tolerance"
+    assert torch.equal(run(x * 2), y * 2)
+
+
 # ---- K split over blocks (workspace) -----------------------------------------------------------------
 @pytest.mark.parametrize("T", [1, 7, 16, 40, 100])
 @pytest.mark.parametrize("ksplit", [2, 3, 4, 8])
