@@ -324,6 +324,51 @@ def time_neighbours(T, device, dtype, world, cfg=LLAMA3_8B, reps=5):
     return out
 
 
+def layer_chain(stack, T, device, dtype, cfg=LLAMA3_8B, reps=5):
+    """The linears with their element-wise neighbours as a decoder layer chains them (models/llama.py:89-93,
+    :272-284): add + norm -> qkv_proj -> o_proj (the query heads stand in for the attention output) -> add + norm ->
+    gate_up_proj with SiLU-and-mul -> down_proj, for every layer, one HIP-graph replay; best of `reps`."""
+    from vllm_pq_amd.host.layers import RMSNorm
+    hidden = cfg["hidden"]
+    norms = []
+    for _ in stack:
+        pair = (RMSNorm(hidden, 1e-5).to(device), RMSNorm(hidden, 1e-5).to(device))
+        for n in pair:
+            n.weight.data = n.weight.data.to(dtype)
+        norms.append(pair)
+    x0 = torch.randn(T, hidden, device=device).to(dtype)
+    q = cfg["heads"] * cfg["head_dim"]
+
+    def step():
+        h, res = x0.clone(), x0.clone()
+        for blk, (n1, n2) in zip(stack, norms):
+            h, res = n1(h, res)
+            qkv, _ = blk["qkv_proj"](h)
+            h, _ = blk["o_proj"](qkv[:, :q])
+            h, res = n2(h, res)
+            gu = blk["gate_up_proj"]
+            a = gu.quant_method.apply_silu_and_mul(gu, h)
+            h, _ = blk["down_proj"](a)
+        return h
+
+    step()
+    torch.cuda.synchronize()
+    g = Graph(step)
+    g.replay()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return {"ms": best, "layers": len(stack), "steps_per_layer": ["fused_add_rms_norm", "qkv_proj", "o_proj",
+                                                                 "fused_add_rms_norm", "gate_up_proj+silu_and_mul",
+                                                                 "down_proj"], "launch": "hipgraph"}
+
+
 def profiled_traffic(key):
     """HBM bytes per launch of a kernel as measured by the committed rocprofv3 counter passes
     (profiles/traffic_r*.json, newest round first); None when that launch was not profiled."""
@@ -489,6 +534,12 @@ def main():
         if not args.no_decode and args.decode_tokens != T:
             neighbours[f"T{args.decode_tokens}"] = time_neighbours(args.decode_tokens, device, dtype, world)
 
+    chain = None
+    if world == 1 and not args.no_neighbours:
+        chain = {f"T{T}": layer_chain(stack, T, device, dtype)}
+        if not args.no_decode and args.decode_tokens != T:
+            chain[f"T{args.decode_tokens}"] = layer_chain(stack, args.decode_tokens, device, dtype)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(T, dtype)
@@ -507,6 +558,7 @@ def main():
                        "apply_calls_per_step": 4 * len(stack)},
             "hbm_gbps": main_m["gbps"], "tokens_per_s": main_m["tokens_per_s"],
             "roofline": roof, "cpu_baseline": cpu, "decode": decode, "neighbours": neighbours,
+            "layer_chain": chain,
         }
         if main_m["split"]:
             line.update(main_m["split"])

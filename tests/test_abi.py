@@ -70,6 +70,8 @@ def test_packed_size_and_kernel_choice():
     assert L.pq_packed_codes_bytes(pa, 3, 6144, 512, 1, 256, 8, 1) == (6144 // 16) * 8 * 1024
     assert L.pq_packed_codes_bytes(_lib.parts_array([40, 24]), 2, 64, 16, 1, 256, 8, 1) == 0    # partitions % 16
     assert L.pq_packed_codes_bytes(_lib.parts_array([64]), 1, 64, 64, 1, 65536, 8, 2) == 0      # K too large for LDS
+    assert L.pq_packed_codes_bytes(_lib.parts_array([64]), 1, 64, 6, 1, 256, 2, 1) == 0         # rows of 12 features
+    assert L.pq_packed_codes_bytes(_lib.parts_array([64]), 1, 64, 8, 1, 256, 2, 1) > 0          # rows of 16
     from vllm_pq_amd import ops
     name = ops.gemm_kernel_name
     assert name(1, 6144, 512, 1, 256, 8, 1, torch.bfloat16, [4096, 1024, 1024], packed=True) == "mfma_decode_packed"

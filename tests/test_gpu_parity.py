@@ -609,3 +609,20 @@ def test_codebook_too_large_for_lds_takes_the_dequant_route(ops, T, bias):
     else:
         ref = orc.gemm(a["x"], a["codes"], a["codebooks"], a["scales"], parts, a["bias"], "fp16", order=1 if not bias else 0)
         assert_close_to_reference_order(bits_of(y), ref, "fp16", "dequant route")
+
+
+def test_row_length_not_a_multiple_of_8_keeps_the_reference_layout(ops):
+    """in_features = 12 (d = 2, 6 groups): no packed layout (rows of x could not start 16-byte aligned), and the
+    layer runs on the reference layout through the linear method -- against the oracle."""
+    from vllm_pq_amd import PQConfig, PQLinearMethod
+    p = Problem(77, 256, 2, 1, [32], 12, 5, "bf16", bias=True).to(DEV)
+    assert ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, [32]) is None
+    layer = torch.nn.Module()
+    m = PQLinearMethod(PQConfig(2, 8, 1, 1))
+    m.create_weights(layer, 12, [32], 12, 32, torch.bfloat16)
+    layer.codes.data, layer.codebooks.data, layer.scales.data = p.codes_dev, p.codebooks_dev, p.scales_dev
+    m.process_weights_after_loading(layer)
+    assert layer.pq_packed_codes is None
+    y = m.apply(layer, p.x_dev, p.bias_dev)
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(y), y32, "bf16", "unpacked fallback")

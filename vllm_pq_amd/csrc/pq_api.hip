@@ -209,7 +209,7 @@ static int run_gemm(const char *fn, bool packed, const void *x, int32_t T, int64
     a.workspace = workspace;
     a.workspace_bytes = workspace_bytes;
     a.packed = packed;
-    if (packed && !pq::packable(a.parts, d, K, M, code_bytes))
+    if (packed && !pq::packable(a.parts, G, d, K, M, code_bytes))
         return fail(PQ_ERR_UNSUPPORTED, "%s: this format has no packed layout (pq_packed_codes_bytes() == 0)", fn);
     const Kernel k = choose(a);
     if (packed && k == K_GENERIC)
@@ -297,7 +297,7 @@ size_t pq_packed_codes_bytes(const int32_t *part_sizes, int32_t num_parts, int32
     pq::Parts parts;
     if (check_format("pq_packed_codes_bytes", part_sizes, num_parts, N, G, M, K, d, code_bytes, PQ_DTYPE_BF16, &parts))
         return 0;
-    if (!pq::packable(parts, d, K, M, code_bytes)) return 0;
+    if (!pq::packable(parts, G, d, K, M, code_bytes)) return 0;
     return pq::packed_bytes(N, G, M, code_bytes);
 }
 
@@ -306,7 +306,7 @@ int pq_repack_codes(const void *codes, const int32_t *part_sizes, int32_t num_pa
     pq::Parts parts;
     int rc = check_format("pq_repack_codes", part_sizes, num_parts, N, G, M, K, d, code_bytes, PQ_DTYPE_BF16, &parts);
     if (rc) return rc;
-    if (!pq::packable(parts, d, K, M, code_bytes))
+    if (!pq::packable(parts, G, d, K, M, code_bytes))
         return fail(PQ_ERR_UNSUPPORTED, "pq_repack_codes: this format has no packed layout");
     if (N == 0 || G == 0) return PQ_OK;
     if (!codes || !packed_codes) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_repack_codes: NULL tensor pointer");
@@ -328,7 +328,7 @@ int pq_gemm_kernel_name(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, i
     if (rc) return rc;
     if (!buf || buf_len == 0) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_gemm_kernel_name: no buffer");
     a.packed = packed != 0;
-    if (a.packed && !pq::packable(a.parts, d, K, M, code_bytes))
+    if (a.packed && !pq::packable(a.parts, G, d, K, M, code_bytes))
         return fail(PQ_ERR_UNSUPPORTED, "pq_gemm_kernel_name: this format has no packed layout");
     static const char *names[] = {"generic", "mfma_stream", "mfma_tiled", "mfma_decode"};
     snprintf(buf, buf_len, "%s%s", names[choose(a)], a.packed ? "_packed" : "");
@@ -410,7 +410,7 @@ int pq_gemm_silu_mul_is_fused(int32_t T, int32_t I, int32_t G, int32_t K, int32_
     if (fill_gate_up(a, "pq_gemm_silu_mul_is_fused", al, T, (int64_t)G * d, al, al, al, nullptr, I, G, K, d, code_bytes,
                      dtype, al, I))
         return 0;
-    return pq::packable(a.parts, d, K, 1, code_bytes) && pq::gemm_stream_act_supported(a) ? 1 : 0;
+    return pq::packable(a.parts, G, d, K, 1, code_bytes) && pq::gemm_stream_act_supported(a) ? 1 : 0;
 }
 
 int pq_gemm_packed_silu_mul(const void *x, int32_t T, int64_t x_row_stride, const void *packed_codes,
@@ -424,7 +424,7 @@ int pq_gemm_packed_silu_mul(const void *x, int32_t T, int64_t x_row_stride, cons
     if (rc) return rc;
     if (T == 0 || I == 0) return PQ_OK;
     if (!y || !scales || !x || !packed_codes || !codebooks) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: NULL tensor pointer", fn);
-    if (!pq::packable(a.parts, d, K, 1, code_bytes))
+    if (!pq::packable(a.parts, G, d, K, 1, code_bytes))
         return fail(PQ_ERR_UNSUPPORTED, "%s: this format has no packed layout (pq_packed_codes_bytes() == 0)", fn);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (pq::gemm_stream_act_supported(a)) {

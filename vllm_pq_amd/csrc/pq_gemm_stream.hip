@@ -241,8 +241,9 @@ hipError_t launch_gemm_stream(const GemmArgs &a, hipStream_t stream) {
 }
 
 // ---- re-layout ------------------------------------------------------------------------------------
-bool packable(const Parts &parts, int d, int K, int M, int code_bytes) {
+bool packable(const Parts &parts, int G, int d, int K, int M, int code_bytes) {
     if (!stream_format_supported(d, K, M, code_bytes)) return false;
+    if (((long)G * d) % 8) return false;        // rows of x (at least G * d long) must be able to start 16-byte aligned
     for (int p = 0; p < parts.num; ++p)
         if (parts.size[p] % 16) return false;   // fragments must not straddle two codebooks
     return true;

@@ -10,7 +10,7 @@ hipError_t launch_gemm_tiled_fp16(const GemmArgs &a, hipStream_t stream);
 // Needs the PACKED code order, 16-byte aligned operands and a format the LDS image can hold.
 bool gemm_tiled_supported(const GemmArgs &a) {
     if (!a.packed) return false;
-    if (!packable(a.parts, a.d, a.K, a.M, a.code_bytes)) return false;
+    if (!packable(a.parts, a.G, a.d, a.K, a.M, a.code_bytes)) return false;
     // activations are staged in whole 64-feature tiles, codes consumed in register pieces of one or two
     // tiles (the tile shapes with several tiles per ring stage ask for more and are skipped when Kin does
     // not divide)

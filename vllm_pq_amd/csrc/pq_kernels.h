@@ -76,7 +76,7 @@ hipError_t launch_gemm_decode(const GemmArgs &a, hipStream_t stream);
 
 // Load-time re-layout of the codes for the MFMA kernels.
 bool stream_format_supported(int d, int K, int M, int code_bytes);
-bool packable(const Parts &parts, int d, int K, int M, int code_bytes);
+bool packable(const Parts &parts, int G, int d, int K, int M, int code_bytes);
 size_t packed_bytes(int N, int G, int M, int code_bytes);
 hipError_t launch_repack(const void *codes, int N, int G, int M, int K, int d, int code_bytes, void *packed,
                          hipStream_t stream);
