@@ -46,7 +46,7 @@ static void run(const Shape &sh, int T, int waves_force, int nf_force, bool stam
     DecodeParams p;
     p.x = (const unsigned char *)x; p.codebooks = (const unsigned char *)cb; p.scales = (const uint16_t *)sc; p.bias = nullptr;
     p.y = (uint16_t *)y; p.y_stride = N; p.x_stride_bytes = sh.Kin * 2; p.T = T; p.nchunks = nchunks; p.K = K; p.nf = g.nf;
-    p.wk_log2 = g.wk_log2; p.img_bytes = K * 256; p.spt = K * 16 >= g.waves * 64 ? K * 16 / (g.waves * 64) : 1;
+    p.wk_log2 = g.wk_log2; p.img_bytes = K * 256; p.spt = K * 16 >= g.waves * 64 ? K * 16 / (g.waves * 64) : 1; p.codes_early = codes_first;
     const int rows = (g.waves >> g.wk_log2) * g.nf * 16;
     p.tmap = make_tile_map(a.parts, rows);
     const int nblk = tiles_in(a.parts, rows);
@@ -78,7 +78,7 @@ static void run(const Shape &sh, int T, int waves_force, int nf_force, bool stam
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / nrep;
     const double bytes = (double)N * G + (double)sh.nparts * K * 16 + N * 2.0 + (double)T * sh.Kin * 2 + (double)T * N * 2;
-    printf("%-16s%s T=%2d N=%5d Kin=%5d waves=%d wk=%d nf=%d c=%d blocks=%4d: %6.2f us/launch  %6.0f GB/s  (%.3f of 8 TB/s)\n", sh.name, codes_first ? " [codes first]" : "", T, N,
+    printf("%-16s%s T=%2d N=%5d Kin=%5d waves=%d wk=%d nf=%d c=%d blocks=%4d: %6.2f us/launch  %6.0f GB/s  (%.3f of 8 TB/s)\n", sh.name, codes_first ? " [codes early]" : "", T, N,
            sh.Kin, g.waves, 1 << g.wk_log2, g.nf, g.c, nblk, us, bytes / us * 1e-3, bytes / us * 1e-3 / 8000.0);
     if (stamps) {
         for (int i = 0; i < 4; ++i) { launch(i, true); CK(hipDeviceSynchronize()); }
@@ -111,6 +111,11 @@ int main(int argc, char **argv) {
         {"70B/tp8.gate_up", 2, {3584, 3584, 0}, 8192}, {"70B/tp8.down", 1, {8192, 0, 0}, 3584}};
     for (const Shape &sh : shapes) run(sh, 16, 0, 0, stamps);
     run(shapes[2], 1, 0, 0, stamps);
+    printf("---- code pieces requested right behind the activations ----\n");
+    for (const Shape &sh : shapes) run(sh, 16, 0, 0, stamps && (&sh == &shapes[2]), 1);
+    run(shapes[2], 1, 0, 0, stamps, 1);
+    run(shapes[1], 1, 0, 0, false, 0);
+    run(shapes[1], 1, 0, 0, false, 1);
     // alternatives for the big ones
     run(shapes[2], 16, 8, 8, false);
     run(shapes[0], 16, 8, 1, false);

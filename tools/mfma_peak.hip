@@ -35,6 +35,37 @@ __global__ __launch_bounds__(512) void mfma_loop(const uint4 *__restrict__ in, f
     out[gid] = s;
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// the same with v_mfma_f32_32x32x16_bf16: twice the MACs per operand register read
+__global__ __launch_bounds__(512) void mfma_loop32(const uint4 *__restrict__ in, float *__restrict__ out, int iters) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    bf16x8 a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a[i] = __builtin_bit_cast(bf16x8, in[(gid * 8 + i) & 0xffff]);
+        b[i] = __builtin_bit_cast(bf16x8, in[(gid * 8 + 4 + i) & 0xffff]);
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i * 2 + j], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += acc[i][k];
+    out[gid] = s;
+}
+
 int main() {
     const int blocks = 256, threads = 512, iters = 20000;
     uint4 *in;
@@ -64,7 +95,17 @@ int main() {
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         const double flops = (double)reps * blocks * (threads / 64) * iters * 16.0 * 16384.0;
-        printf("%s operands: %.1f TFLOP/s (%.2f ms per launch)\n", mode == 0 ? "random" : "zero  ", flops / (ms * 1e-3) / 1e12,
+        printf("16x16x32, %s operands: %.1f TFLOP/s (%.2f ms per launch)\n", mode == 0 ? "random" : "zero  ", flops / (ms * 1e-3) / 1e12,
+               ms / reps);
+        for (int w = 0; w < 30; ++w) hipLaunchKernelGGL(mfma_loop32, dim3(blocks), dim3(threads), 0, 0, in, out, iters);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mfma_loop32, dim3(blocks), dim3(threads), 0, 0, in, out, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flops32 = (double)reps * blocks * (threads / 64) * iters * 4.0 * 32768.0;
+        printf("32x32x16, %s operands: %.1f TFLOP/s (%.2f ms per launch)\n", mode == 0 ? "random" : "zero  ", flops32 / (ms * 1e-3) / 1e12,
                ms / reps);
     }
     return 0;

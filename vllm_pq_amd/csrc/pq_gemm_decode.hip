@@ -79,6 +79,7 @@ static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipSt
     p.wk_log2 = g.wk_log2;
     p.img_bytes = (uint32_t)a.K * 256u;
     p.spt = a.K * 16 >= g.waves * 64 ? a.K * 16 / (g.waves * 64) : 1;
+    p.codes_early = 0;
     const int rows = (g.waves >> g.wk_log2) * g.nf * 16;
     p.tmap = make_tile_map(a.parts, rows);
     const dim3 grid(tiles_in(a.parts, rows));

@@ -51,6 +51,7 @@ struct DecodeParams {
     int wk_log2;                   // log2 of the waves along K
     uint32_t img_bytes;            // K * 256, the staging area follows
     int spt;                       // 16-byte image slots per thread: max(1, K * 16 / threads per block)
+    int codes_early;               // request the code pieces right behind the activations instead of after the barrier
     TileMap tmap;                  // tiles of (blockDim/64 >> wk_log2) * nf * 16 rows
 };
 
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     } else {
         ++issued;
     }
+    const int seq_cb = issued - 1;                // sequence number of the last entry load
 
     // ---- activations and code pieces.  MFMA k-step s wants lane (q = l >> 4, c = l & 15) to hold
     // x[token c][32 s + 8 q .. + 7]: 16 rows x 64 bytes per wave-load, which the memory pipeline serves far slower than
@@ -217,10 +219,16 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
 #undef DC_XP
     issued += 16;
     const int seq_xa = issued - 1;                // sequence number of the set's last load
+    int seq_dma0 = issued;
+    if (p.codes_early) {
+#pragma nounroll
+        for (int j = 0; j < U; ++j) issue_dma(j);
+        issued += U;
+    }
     DC_STAMP(2)   // entries and activations requested
 
     // ---- codebook image, stored while the memory pipeline works through the activation loads
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the entries are the oldest requests: 16 loads behind them
+    dc_wait_vm(issued - 1 - seq_cb);               // the entries are the oldest requests
     dc_landed(cbv0);
     DC_STAMP(3)   // entries landed
     if (img_active) {
@@ -263,10 +271,12 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     DC_STAMP(5)   // barrier
 
     // ---- code pieces, epilogue operands
-    const int seq_dma0 = issued;
+    if (!p.codes_early) {
+        seq_dma0 = issued;
 #pragma nounroll
-    for (int j = 0; j < U; ++j) issue_dma(j);
-    issued += U;
+        for (int j = 0; j < U; ++j) issue_dma(j);
+        issued += U;
+    }
     // wave (wk, wr) with wk < nf finishes fragment wk of row group wr: token lane & 15, rows 4 (lane >> 4) .. + 3
     const int out_frag = wr * nf + wk;
     const bool out_wave = wk < nf && out_frag < nfr;
