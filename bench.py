@@ -93,26 +93,37 @@ LAUNCH_LOG = None
 
 
 def enable_launch_log(stack, dtype):
+    """Wraps the operator layer's three GEMM entry points (every PQ GEMM launch of the process goes through one of
+    them, whichever plugin method issued it), so the log holds exactly one record per kernel dispatch."""
     global LAUNCH_LOG
     from vllm_pq_amd import ops
-    from vllm_pq_amd.pq import PQLinearMethod
     LAUNCH_LOG = []
     names = {}
     for name, layer in stack[0].items():
         names[(layer.codes.shape[0], layer.codes.shape[1])] = name
-    plain = PQLinearMethod.apply
 
-    def logged(self, layer, x, bias=None):
-        N, G, M = layer.codes.shape
+    def record(x, codes, codebooks, parts, packed, fused=None):
+        N, G, M = codes.shape
         T = x.numel() // x.shape[-1]
-        parts = getattr(layer.codebooks, "output_partition_sizes", [])
-        kern = ops.gemm_kernel_name(T, N, G, M, layer.codebooks.shape[1], layer.codebooks.shape[3],
-                                    layer.codes.element_size(), dtype, parts,
-                                    packed=getattr(layer, "pq_packed_codes", None) is not None)
-        LAUNCH_LOG.append([names.get((N, G), "?"), T, N, G * layer.codebooks.shape[3], kern])
-        return plain(self, layer, x, bias)
+        kern = ops.gemm_kernel_name(T, N, G, M, codebooks.shape[1], codebooks.shape[3], codes.element_size(),
+                                    dtype, list(parts) or [N], packed=packed) + (fused or "")
+        LAUNCH_LOG.append([names.get((N, G), "?"), T, N, G * codebooks.shape[3], kern])
 
-    PQLinearMethod.apply = logged
+    plain, packed, fused = ops.pq_gemm, ops.pq_gemm_packed, ops.pq_gemm_packed_silu_mul
+
+    def gemm(input, codes, codebooks, scales, codebook_partition_sizes, bias=None):
+        record(input, codes, codebooks, codebook_partition_sizes, False)
+        return plain(input, codes, codebooks, scales, codebook_partition_sizes, bias)
+
+    def gemm_packed(input, packed_codes, codes, codebooks, scales, codebook_partition_sizes, bias=None):
+        record(input, codes, codebooks, codebook_partition_sizes, True)
+        return packed(input, packed_codes, codes, codebooks, scales, codebook_partition_sizes, bias)
+
+    def gemm_packed_silu_mul(input, packed_codes, codes, codebooks, scales, bias=None):
+        record(input, codes, codebooks, [codes.shape[0] // 2] * 2, True, fused="+silu_mul")
+        return fused(input, packed_codes, codes, codebooks, scales, bias)
+
+    ops.pq_gemm, ops.pq_gemm_packed, ops.pq_gemm_packed_silu_mul = gemm, gemm_packed, gemm_packed_silu_mul
 
 
 class Graph:
