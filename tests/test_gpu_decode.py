@@ -41,7 +41,7 @@ def _run(ops, monkeypatch, p, parts, cfg):
     (3584, "8x1"), (3584, "8x7"),                              # seven chunks on eight waves
     (4096, "8x1"), (4096, "8x7"), (4096, "8x8"),
 ])
-@pytest.mark.parametrize("T", [1, 5, 16])
+@pytest.mark.parametrize("T", [1, 5, 8, 9, 16])
 def test_decode_kernel_every_geometry(ops, monkeypatch, Kin, cfg, T):
     parts = [208, 112, 16]          # partial tiles for every rows-per-block, a one-fragment partition
     p = Problem(1000 + Kin // 512, 256, 8, 1, parts, Kin, T, "bf16", bias=(T != 5)).to(DEV)
@@ -58,6 +58,37 @@ def test_decode_kernel_codebook_sizes(ops, monkeypatch, K, dtype):
     y = _run(ops, monkeypatch, p, parts, None)
     _, y32 = p.oracle_gemm(order=2)
     assert_close_to_exact(bits_of(y), y32, dtype, f"decode K={K} {dtype}")
+
+
+# K longer than the 8 chunks of one block: 9 chunks -> 2 blocks of 5 and 4, 16 -> 2 x 8, 28 -> 4 x 7, 64 -> 8 x 8
+@pytest.mark.parametrize("Kin,cfg", [(4608, None), (4608, "8x3"), (8192, None), (8192, "8x8"), (14336, None),
+                                     (14336, "8x2"), (32768, "8x1")])
+@pytest.mark.parametrize("T", [1, 8, 13, 16])
+def test_decode_kernel_k_split_over_blocks(ops, monkeypatch, Kin, cfg, T):
+    parts = [208, 112, 16]
+    ops.ensure_workspace(torch.device(DEV))
+    p = Problem(2000 + Kin // 512 + T, 256, 8, 1, parts, Kin, T, "bf16", bias=(T != 8)).to(DEV)
+    y = _run(ops, monkeypatch, p, parts, cfg)
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(y), y32, "bf16", f"decode K split Kin={Kin} cfg={cfg} T={T}")
+
+
+def test_decode_kernel_long_k_without_workspace_is_the_stream_kernels(ops):
+    """Without a workspace a K of more than 4096 cannot be split over blocks: the library says so through the
+    kernel it names for a launch that has none, and still computes the layer."""
+    parts, Kin, T = [256], 8192, 16
+    p = Problem(77, 256, 8, 1, parts, Kin, T, "bf16").to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    ops.ensure_workspace(torch.device(DEV))
+    want = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)
+    ops.drop_workspace()
+    try:
+        got = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, None)
+    finally:
+        ops.ensure_workspace(torch.device(DEV))
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(got), y32, "bf16", "long K, no workspace")
+    assert_close_to_exact(bits_of(want), y32, "bf16", "long K, workspace")
 
 
 def test_decode_kernel_edge_codes_and_one_hot(ops, monkeypatch):
@@ -106,8 +137,10 @@ def test_decode_kernel_model_shapes_full_size(ops, name, parts, Kin, T):
     x = torch.randn(T, Kin, device=DEV).to(torch.bfloat16)
     packed = ops.pq_repack_codes(codes, cb, parts)
     name = ops.gemm_kernel_name(T, N, G, 1, 256, 8, 1, x.dtype, parts, packed=True)
-    # the decode kernel where it is the faster one: at most 4096 inputs, and four chunks or more than 4096 rows
-    decode = Kin <= 4096 and (Kin // 512 > 2 or N > 4096)
+    # the decode kernel where it is the faster one: three chunks or more, or more than 4096 rows; K longer than
+    # 4096 (split over blocks through the workspace a loaded layer has) up to 8 tokens
+    ops.ensure_workspace(torch.device(DEV))
+    decode = (Kin // 512 > 2 or N > 4096) if Kin <= 4096 else T <= 8
     assert name == ("mfma_decode_packed" if decode else "mfma_stream_packed")
     y = ops.pq_gemm_packed(x, packed, codes, cb, scales, parts, None)
     w = ops.pq_dequant(codes, cb, parts)

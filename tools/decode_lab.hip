@@ -39,7 +39,9 @@ static void run(const Shape &sh, int T, int waves_force, int nf_force, bool stam
     CK(hipMalloc(&y, (size_t)T * N * 2));
     a.x = x; a.T = T; a.x_stride = sh.Kin; a.codes = pk[0]; a.codebooks = cb; a.scales = sc; a.bias = nullptr;
     a.N = N; a.G = G; a.M = 1; a.K = K; a.d = 8; a.code_bytes = 1; a.dtype = PQ_DTYPE_BF16; a.y = y; a.y_stride = N;
-    a.workspace = nullptr; a.workspace_bytes = 0; a.packed = true;
+    static void *ws = nullptr;   // K-split scratch (counters start at zero and every launch leaves them at zero)
+    if (!ws) { CK(hipMalloc(&ws, WS_COUNTER_BYTES + WS_PARTIAL_BYTES)); CK(hipMemset(ws, 0, WS_COUNTER_BYTES + WS_PARTIAL_BYTES)); }
+    a.workspace = ws; a.workspace_bytes = WS_COUNTER_BYTES + WS_PARTIAL_BYTES; a.packed = true;
     DecodeGeom g = choose_decode_geom(a);
     if (g.nf == 0) { printf("%-16s Kin=%d: not taken by the decode kernel\n", sh.name, sh.Kin); return; }
     if (waves_force) { g.waves = waves_force; g.nf = nf_force; }
@@ -47,16 +49,18 @@ static void run(const Shape &sh, int T, int waves_force, int nf_force, bool stam
     p.x = (const unsigned char *)x; p.codebooks = (const unsigned char *)cb; p.scales = (const uint16_t *)sc; p.bias = nullptr;
     p.y = (uint16_t *)y; p.y_stride = N; p.x_stride_bytes = sh.Kin * 2; p.T = T; p.nchunks = nchunks; p.K = K; p.nf = g.nf;
     p.wk_log2 = g.wk_log2; p.img_bytes = K * 256; p.spt = K * 16 >= g.waves * 64 ? K * 16 / (g.waves * 64) : 1; p.codes_early = codes_first;
+    p.ksplit = g.ksplit; p.cpb = g.cpb; p.n_total = N; p.ws_cnt = (unsigned *)a.workspace;
+    p.ws_part = (float *)((unsigned char *)a.workspace + WS_COUNTER_BYTES);
     const int rows = (g.waves >> g.wk_log2) * g.nf * 16;
     p.tmap = make_tile_map(a.parts, rows);
-    const int nblk = tiles_in(a.parts, rows);
+    const int ntile = tiles_in(a.parts, rows), nblk = ntile * g.ksplit;
     const size_t lds = (size_t)p.img_bytes + (size_t)g.waves * DC_UMAX * 1024;
     CK(hipMalloc(&st, (size_t)nblk * 192)); CK(hipMemset(st, 0, (size_t)nblk * 192));
     auto launch = [&](int i, bool stamped) {
         p.codes = (const unsigned char *)pk[i % copies];
         p.bias = stamped ? (const uint16_t *)st : nullptr;
-        if (stamped) hipLaunchKernelGGL((gemm_decode_kernel<bf16_t, true>), dim3(nblk), dim3(g.waves * 64), lds, 0, p);
-        else hipLaunchKernelGGL((gemm_decode_kernel<bf16_t, false>), dim3(nblk), dim3(g.waves * 64), lds, 0, p);
+        if (stamped) hipLaunchKernelGGL((gemm_decode_kernel<bf16_t, true>), dim3(ntile, g.ksplit), dim3(g.waves * 64), lds, 0, p);
+        else hipLaunchKernelGGL((gemm_decode_kernel<bf16_t, false>), dim3(ntile, g.ksplit), dim3(g.waves * 64), lds, 0, p);
     };
     static bool attr = false;
     if (!attr) {

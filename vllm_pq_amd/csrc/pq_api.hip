@@ -171,7 +171,9 @@ int pq_embedding(const int64_t *ids, int32_t T, const void *codes, const void *c
 size_t pq_gemm_workspace_bytes(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes,
                                int32_t /*dtype*/) {
     if (T <= 0 || N <= 0 || G <= 0) return 0;
-    return pq::stream_workspace_bytes(T, N, G, M, K, d, code_bytes);
+    const size_t st = pq::stream_workspace_bytes(T, N, G, M, K, d, code_bytes);
+    const size_t dc = pq::decode_workspace_bytes(T, N, G, M, K, d, code_bytes);
+    return st > dc ? st : dc;
 }
 
 size_t pq_gemm_workspace_max_bytes(void) { return pq::WS_COUNTER_BYTES + pq::WS_PARTIAL_BYTES; }
@@ -217,7 +219,8 @@ static int run_gemm(const char *fn, bool packed, const void *x, int32_t T, int64
                     "%s: x, codebooks and packed_codes must be 16-byte aligned and x_row_stride a multiple of 8", fn);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e;
-    if (clear_counters && k == K_STREAM && pq::choose_stream_cfg(a, nullptr).ksplit > 1) {
+    if (clear_counters && ((k == K_STREAM && pq::choose_stream_cfg(a, nullptr).ksplit > 1) ||
+                           (k == K_DECODE && pq::choose_decode_geom(a).ksplit > 1))) {
         // a workspace other calls have used: the arrival counters at its head start this launch at zero
         e = hipMemsetAsync(workspace, 0, pq::WS_COUNTER_BYTES, s);
         if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "%s: clearing the scratch counters: %s", fn, hipGetErrorString(e));
@@ -280,7 +283,9 @@ int pq_gemm_packed_noalloc(const void *x, int32_t T, int64_t x_row_stride, const
     const char *fn = "pq_gemm_packed_noalloc";
     void *ptr = nullptr;
     if (T > 0 && N > 0 && G > 0) {
-        const size_t want = pq::stream_preferred_workspace_bytes(T, N, G, M, K, d, code_bytes);
+        size_t want = pq::stream_preferred_workspace_bytes(T, N, G, M, K, d, code_bytes);
+        const size_t want_dc = pq::decode_workspace_bytes(T, N, G, M, K, d, code_bytes);
+        if (want_dc > want) want = want_dc;
         if (want > SCRATCH_BYTES)
             return fail(PQ_ERR_WORKSPACE, "%s: T=%d x N=%d with %d input groups splits K with %zu bytes of scratch, the "
                         "built-in buffer holds %zu: use pq_gemm_packed with a workspace of the caller's, or a smaller batch",
@@ -328,6 +333,9 @@ int pq_gemm_kernel_name(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, i
     if (rc) return rc;
     if (!buf || buf_len == 0) return fail(PQ_ERR_INVALID_ARGUMENT, "pq_gemm_kernel_name: no buffer");
     a.packed = packed != 0;
+    // the choice for a launch that brings the full-size workspace, as a loaded layer's launches do
+    a.workspace = al;
+    a.workspace_bytes = pq::WS_COUNTER_BYTES + pq::WS_PARTIAL_BYTES;
     if (a.packed && !pq::packable(a.parts, G, d, K, M, code_bytes))
         return fail(PQ_ERR_UNSUPPORTED, "pq_gemm_kernel_name: this format has no packed layout");
     static const char *names[] = {"generic", "mfma_stream", "mfma_tiled", "mfma_decode"};

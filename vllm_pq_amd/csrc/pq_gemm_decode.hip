@@ -18,14 +18,39 @@ bool gemm_decode_supported(const GemmArgs &a) {
     if (a.y_stride % 4) return false;
     for (int p = 0; p < a.parts.num; ++p)
         if (a.parts.size[p] % 16) return false;
-    return a.G / 64 <= DC_MAX_WAVES;             // one chunk per wave: K <= 4096
+    if (a.G / 64 <= DC_MAX_WAVES) return true;   // one chunk per wave: K <= 4096
+    return choose_decode_geom(a).nf > 0;         // longer K: split over blocks, which needs the workspace
 }
 
 // Measured against the K-split stream kernel on the same launches (tools/decode_ab.py): ahead by 0.1 - 0.6 us wherever
-// a block has at least four chunks or the grid fills the chip; short-K layers of few rows are the stream kernel's.
+// a block has at least three chunks or the grid fills the chip; short-K layers of few rows are the stream kernel's.
+// With at most 8 tokens it loads half the activation registers and is ahead by 0.5 - 1.1 us (10 - 20 %), K split over
+// blocks included; a split K at 9..16 tokens is level with the stream kernel's split (within 0.3 us either way) and
+// stays there.
 bool gemm_decode_preferred(const GemmArgs &a) {
     if (!gemm_decode_supported(a)) return false;
+    if (a.G / 64 > DC_MAX_WAVES) return a.T <= 8;
     return a.G / 64 > 2 || a.N > 4096;
+}
+
+// Blocks per tile for K longer than a block's 8 chunks: the fewest that cover K with at most 8 chunks each and,
+// beyond that, as many as still leave every tile's grid within one round of the chip (each block then reads a
+// shorter slice of x); 1 without a workspace that holds the partial sums.
+static int decode_ksplit(const GemmArgs &a, int nchunks) {
+    if (nchunks <= DC_MAX_WAVES) return 1;
+    const int need = (nchunks + DC_MAX_WAVES - 1) / DC_MAX_WAVES;
+    if (need > 8) return 0;
+    if (!a.workspace || reinterpret_cast<uintptr_t>(a.workspace) & 15) return 0;
+    if (a.workspace_bytes < WS_COUNTER_BYTES + (size_t)need * a.T * a.N * 4) return 0;
+    return need;
+}
+
+size_t decode_workspace_bytes(int T, int N, int G, int M, int K, int d, int code_bytes) {
+    if (d != 8 || M != 1 || code_bytes != 1 || K < 16 || K > 256 || T < 1 || T > 16 || G % 64) return 0;
+    const int nchunks = G / 64;
+    if (nchunks <= DC_MAX_WAVES || nchunks > 8 * DC_MAX_WAVES) return 0;
+    const size_t part = (size_t)((nchunks + DC_MAX_WAVES - 1) / DC_MAX_WAVES) * T * N * 4;
+    return part > WS_PARTIAL_BYTES ? 0 : WS_COUNTER_BYTES + part;
 }
 
 // Waves along K: as many as there are chunks, up to 8 (a power of two; three chunks take four waves).  Then the
@@ -34,10 +59,12 @@ bool gemm_decode_preferred(const GemmArgs &a) {
 DecodeGeom choose_decode_geom(const GemmArgs &a) {
     const int nchunks = a.G / 64;
     DecodeGeom g;
-    g.wk_log2 = nchunks >= 5 ? 3 : nchunks >= 3 ? 2 : nchunks >= 2 ? 1 : 0;
-    const int WK = 1 << g.wk_log2;
     g.c = 1;
-    if (nchunks > WK) { g.nf = 0; g.waves = 0; return g; }    // K > 4096: not taken
+    g.ksplit = decode_ksplit(a, nchunks);
+    if (g.ksplit == 0) { g.nf = 0; g.waves = 0; g.wk_log2 = 0; g.cpb = 0; return g; }    // not taken
+    g.cpb = (nchunks + g.ksplit - 1) / g.ksplit;              // chunks per block
+    g.wk_log2 = g.cpb >= 5 ? 3 : g.cpb >= 3 ? 2 : g.cpb >= 2 ? 1 : 0;
+    const int WK = 1 << g.wk_log2;
     double best = -1.0;
     g.nf = 1;
     g.waves = WK;
@@ -51,7 +78,8 @@ DecodeGeom choose_decode_geom(const GemmArgs &a) {
     }
     for (int wr = 1; wr * WK <= DC_MAX_WAVES; wr *= 2) {
         for (int nf = 1; nf <= WK && nf * g.c <= DC_UMAX; ++nf) {
-            const long tiles = tiles_in(a.parts, wr * nf * 16);
+            const long tiles = (long)tiles_in(a.parts, wr * nf * 16) * g.ksplit;
+            if (g.ksplit > 1 && tiles / g.ksplit * 4 > (long)WS_COUNTER_BYTES) continue;   // one counter per tile
             const double rounds = (double)((tiles + 255) / 256);
             // fixed: launch ramp, image, epilogue; per unit of a wave about 0.3 us; blocks of few waves share a CU
             const double cost = rounds * (3.0 + 0.3 * nf * g.c) + (tiles < 256 ? 0.002 * (256 - tiles) : 0.0) * nf * g.c;
@@ -80,9 +108,14 @@ static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipSt
     p.img_bytes = (uint32_t)a.K * 256u;
     p.spt = a.K * 16 >= g.waves * 64 ? a.K * 16 / (g.waves * 64) : 1;
     p.codes_early = 0;
+    p.ksplit = g.ksplit;
+    p.cpb = g.cpb;
+    p.n_total = a.N;
+    p.ws_cnt = static_cast<unsigned *>(a.workspace);
+    p.ws_part = g.ksplit > 1 ? reinterpret_cast<float *>(static_cast<unsigned char *>(a.workspace) + WS_COUNTER_BYTES) : nullptr;
     const int rows = (g.waves >> g.wk_log2) * g.nf * 16;
     p.tmap = make_tile_map(a.parts, rows);
-    const dim3 grid(tiles_in(a.parts, rows));
+    const dim3 grid(tiles_in(a.parts, rows), g.ksplit);
     const size_t lds = (size_t)p.img_bytes + (size_t)g.waves * DC_UMAX * 1024;
     auto launch = [&](auto kern) -> hipError_t {
         static std::atomic<bool> attr_set[64];   // per device: more than the default 64 KiB of LDS

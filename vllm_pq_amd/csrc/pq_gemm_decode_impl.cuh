@@ -52,6 +52,13 @@ struct DecodeParams {
     uint32_t img_bytes;            // K * 256, the staging area follows
     int spt;                       // 16-byte image slots per thread: max(1, K * 16 / threads per block)
     int codes_early;               // request the code pieces right behind the activations instead of after the barrier
+    // K split over blocks (longer K than 8 chunks): block (x, y) takes chunks y * cpb .. + cpb - 1 of tile x; the fp32
+    // partial sums [ksplit][T][n_total] meet in the workspace (the streaming kernel's protocol and layout)
+    int ksplit;                    // blocks per tile = gridDim.y (1: no split, no workspace)
+    int cpb;                       // chunks per block (at most 1 << wk_log2)
+    int n_total;                   // output rows of the whole layer
+    float *ws_part;
+    unsigned *ws_cnt;              // one arrival counter per tile, zero between launches
     TileMap tmap;                  // tiles of (blockDim/64 >> wk_log2) * nf * 16 rows
 };
 
@@ -121,6 +128,18 @@ __device__ __forceinline__ u32x4 dc_sel_ror8(const u32x4 &a, const u32x4 &b, uin
     return d;
 }
 
+// d = a rotated by 8 lanes within every row of 16
+__device__ __forceinline__ u32x4 dc_ror8(const u32x4 &a) {
+    u32x4 d;
+    asm("v_mov_b32_dpp %0, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %2, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %3, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
+        : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w)
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));
+    return d;
+}
+
 struct DcX { u32x4 f[16]; };   // the activations of one chunk: k-step s of lane (t, q) = x[t][chunk * 512 + 32 s + 8 q .. + 7]
 
 // STAMPS (diagnostic builds only): thread 0 writes wall-clock stamps of the phases to `bias` (8 x u64 per block)
@@ -154,7 +173,9 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     const int WK = 1 << p.wk_log2;
     const int wk = wave & (WK - 1), wr = wave >> p.wk_log2;
     const int nf = p.nf;
-    const int nck = wk < p.nchunks ? 1 : 0;                   // a wave beyond the last chunk has no work
+    const int chunk0 = (int)blockIdx.y * p.cpb;               // first chunk of this block's K range
+    const int nck_blk = p.nchunks - chunk0 < p.cpb ? p.nchunks - chunk0 : p.cpb;   // chunks in it (at least one)
+    const int nck = wk < nck_blk ? 1 : 0;                     // a wave beyond the last chunk has no work
     const int U = nck * nf;                                   // its units (at most DC_UMAX)
 
     // ---- the block's tile
@@ -201,7 +222,7 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     int fb = wr * nf, nvalid = nfr - fb;           // first fragment of the wave, fragments it really has
     if (nvalid < 1) { fb = nfr - 1; nvalid = 1; }
     const size_t frag_bytes = (size_t)p.nchunks * 1024;
-    const unsigned char *dma_src = p.codes + ((size_t)((loc.row0 >> 4) + fb) * p.nchunks + wk) * 1024;
+    const unsigned char *dma_src = p.codes + ((size_t)((loc.row0 >> 4) + fb) * p.nchunks + chunk0 + wk) * 1024;
     uint32_t dma_dst = stage0;
     int dma_i = 0;
     auto issue_dma = [&](int j) {
@@ -213,11 +234,19 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
         }
     };
     DcX XA;
-    const unsigned char *xb0 = p.x + (size_t)(wk < p.nchunks ? wk : p.nchunks - 1) * 1024;
-#define DC_XP(m) XA.f[2 * (m)] = dc_gload16<128 * (m)>(xoff_a, xb0); XA.f[2 * (m) + 1] = dc_gload16<128 * (m)>(xoff_b, xb0);
-    DC_XP(0) DC_XP(1) DC_XP(2) DC_XP(3) DC_XP(4) DC_XP(5) DC_XP(6) DC_XP(7)
-#undef DC_XP
-    issued += 16;
+    const unsigned char *xb0 = p.x + (size_t)(chunk0 + (wk < nck_blk ? wk : nck_blk - 1)) * 1024;
+    // With at most 8 tokens the second load of every pair (tokens 8..15) is left out: the memory pipeline takes a
+    // wave-load of 1 KiB every 36-40 cycles whatever it holds, and these 8 of a wave's 16 are a microsecond per block.
+    const bool two = p.T > 8;
+#define DC_XA(m) XA.f[2 * (m)] = dc_gload16<128 * (m)>(xoff_a, xb0);
+#define DC_XB(m) XA.f[2 * (m) + 1] = dc_gload16<128 * (m)>(xoff_b, xb0);
+    DC_XA(0) DC_XA(1) DC_XA(2) DC_XA(3) DC_XA(4) DC_XA(5) DC_XA(6) DC_XA(7)
+    if (two) {
+        DC_XB(0) DC_XB(1) DC_XB(2) DC_XB(3) DC_XB(4) DC_XB(5) DC_XB(6) DC_XB(7)
+    }
+#undef DC_XA
+#undef DC_XB
+    issued += two ? 16 : 8;
     const int seq_xa = issued - 1;                // sequence number of the set's last load
     int seq_dma0 = issued;
     if (p.codes_early) {
@@ -291,12 +320,20 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     auto prepare = [&](DcX &X, int seq_x, u32x4 (&B)[16]) {
         dc_wait_vm(issued - 1 - seq_x);
 #define DC_XD(s) dc_landed(X.f[s]);
-        DC_XD(0) DC_XD(1) DC_XD(2) DC_XD(3) DC_XD(4) DC_XD(5) DC_XD(6) DC_XD(7)
-        DC_XD(8) DC_XD(9) DC_XD(10) DC_XD(11) DC_XD(12) DC_XD(13) DC_XD(14) DC_XD(15)
-#undef DC_XD
+        DC_XD(0) DC_XD(2) DC_XD(4) DC_XD(6) DC_XD(8) DC_XD(10) DC_XD(12) DC_XD(14)
+        if (two) {
+            DC_XD(1) DC_XD(3) DC_XD(5) DC_XD(7) DC_XD(9) DC_XD(11) DC_XD(13) DC_XD(15)
 #define DC_XF(m) B[2 * (m)] = dc_sel_ror8(X.f[2 * (m) + 1], X.f[2 * (m)], lo_lanes); B[2 * (m) + 1] = dc_sel_ror8(X.f[2 * (m)], X.f[2 * (m) + 1], hi_lanes);
-        DC_XF(0) DC_XF(1) DC_XF(2) DC_XF(3) DC_XF(4) DC_XF(5) DC_XF(6) DC_XF(7)
+            DC_XF(0) DC_XF(1) DC_XF(2) DC_XF(3) DC_XF(4) DC_XF(5) DC_XF(6) DC_XF(7)
 #undef DC_XF
+        } else {
+            // tokens 0..7 only: the loaded register is k-step 2m as it is (lanes of tokens 8..15 hold other finite
+            // activations; their output columns are never stored), k-step 2m + 1 is the same register rotated
+#define DC_XF(m) B[2 * (m)] = X.f[2 * (m)]; B[2 * (m) + 1] = dc_ror8(X.f[2 * (m)]);
+            DC_XF(0) DC_XF(1) DC_XF(2) DC_XF(3) DC_XF(4) DC_XF(5) DC_XF(6) DC_XF(7)
+#undef DC_XF
+        }
+#undef DC_XD
     };
     u32x4 B0[16];
     prepare(XA, seq_xa, B0);
@@ -365,6 +402,20 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     DC_STAMP(10)   // all waves' units done
 
     // ---- epilogue: the partial sums of the output fragment over the waves along K, in a fixed order -------------------
+    const int t_out = lane & 15;
+    auto finish = [&](const f32x4 &sum) {   // scale, bias, one rounding, 8-byte store (y and its row stride are 8-byte aligned: host)
+        const uint32_t sw[2] = {scv.x, scv.y}, bw[2] = {biv.x, biv.y};
+        uint16_t h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint16_t s16 = (uint16_t)(sw[e >> 1] >> ((e & 1) * 16)), b16 = (uint16_t)(bw[e >> 1] >> ((e & 1) * 16));
+            h[e] = Act<AT>::from_f32(sum[e] * Act<AT>::to_f32(s16) + (bias ? Act<AT>::to_f32(b16) : 0.0f));
+        }
+        u32x2 o2;
+        o2.x = h[0] | ((uint32_t)h[1] << 16);
+        o2.y = h[2] | ((uint32_t)h[3] << 16);
+        *reinterpret_cast<u32x2 *>(p.y + (size_t)t_out * p.y_stride + out_row) = o2;
+    };
     if (out_wave) {
         const unsigned char *slot = smem + p.img_bytes + ((size_t)((wr << p.wk_log2) * DC_UMAX + wk) * 64 + lane) * 16;
         f32x4 sum = *reinterpret_cast<const f32x4 *>(slot);
@@ -373,19 +424,44 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
             const f32x4 v = *reinterpret_cast<const f32x4 *>(slot + (size_t)w * (DC_UMAX * 1024));
             sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
         }
-        const int t = lane & 15;
-        if (t < p.T) {
-            const uint32_t sw[2] = {scv.x, scv.y}, bw[2] = {biv.x, biv.y};
-            uint16_t h[4];
+        if (t_out < p.T) {
+            if (p.ksplit == 1) finish(sum);
+            else coherent_store16(p.ws_part + ((size_t)blockIdx.y * p.T + t_out) * (size_t)p.n_total + out_row, sum);
+        }
+    }
+    // K split over blocks: every block counts itself in on its tile's counter; the last one to arrive adds the partial
+    // sums up in split order (the result does not depend on which block that is), finishes the tile and leaves the
+    // counter at zero.  Partials and counter go past the per-XCD L2 (device-scope relaxed accesses), ordered by waiting
+    // for the stores' completion before the count.
+    if (p.ksplit > 1) {
+        // the flag lives in the first word of the staging area (every accumulator slot has been read before the
+        // barrier below); a static __shared__ variable would move the image off its 64 KiB-aligned base
+        volatile int &s_last = *reinterpret_cast<volatile int *>(smem + p.img_bytes);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned *cnt = p.ws_cnt + blockIdx.x;
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (unsigned)p.ksplit - 1u;
+            if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_last && out_wave && t_out < p.T) {
+            f32x4 part[8];   // all requested before any is waited for; splits past the last re-read the last one
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint16_t s16 = (uint16_t)(sw[e >> 1] >> ((e & 1) * 16)), b16 = (uint16_t)(bw[e >> 1] >> ((e & 1) * 16));
-                h[e] = Act<AT>::from_f32(sum[e] * Act<AT>::to_f32(s16) + (bias ? Act<AT>::to_f32(b16) : 0.0f));
+            for (int z = 0; z < 8; ++z) {
+                const int zc = z < p.ksplit ? z : p.ksplit - 1;
+                part[z] = coherent_load16_issue(p.ws_part + ((size_t)zc * p.T + t_out) * (size_t)p.n_total + out_row);
             }
-            u32x2 o2;   // y and its row stride are 8-byte aligned (checked on the host)
-            o2.x = h[0] | ((uint32_t)h[1] << 16);
-            o2.y = h[2] | ((uint32_t)h[3] << 16);
-            *reinterpret_cast<u32x2 *>(p.y + (size_t)t * p.y_stride + out_row) = o2;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int z = 0; z < 8; ++z) coherent_landed(part[z]);
+            f32x4 sum{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int z = 0; z < 8; ++z) {
+                if (z < p.ksplit) { sum.x += part[z].x; sum.y += part[z].y; sum.z += part[z].z; sum.w += part[z].w; }
+            }
+            finish(sum);
         }
     }
     if constexpr (STAMPS) {
@@ -394,7 +470,7 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
         const int nw = (int)(blockDim.x >> 6);
         if (lane == 0 && (wave == 0 || wave == nw - 1)) {
             unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<uint16_t *>(p.bias)) +
-                                    (size_t)blockIdx.x * 24 + (wave == 0 ? 0 : 12);
+                                    ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 24 + (wave == 0 ? 0 : 12);
 #pragma unroll
             for (int k = 0; k < 12; ++k) o[k] = st[k];
         }

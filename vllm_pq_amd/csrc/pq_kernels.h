@@ -68,7 +68,10 @@ hipError_t launch_gemm_stream_act(const GemmArgs &a, hipStream_t stream);
 // Decode batches (at most 16 tokens; d = 8, one codebook of up to 256 entries, one-byte packed codes, whole
 // 512-feature chunks): pq_gemm_decode_impl.cuh.  `waves` per block, of which 1 << wk_log2 along K; nf fragments
 // and c chunks per wave.  nf == 0: not taken.
-struct DecodeGeom { int nf, wk_log2, c, waves; };
+struct DecodeGeom { int nf, wk_log2, c, waves, ksplit, cpb; };   // ksplit blocks per tile along K, cpb chunks each
+// Bytes of workspace with which a decode batch of this problem runs K-split over blocks (0: K fits one block, or
+// the decode kernel does not take the format).
+size_t decode_workspace_bytes(int T, int N, int G, int M, int K, int d, int code_bytes);
 bool gemm_decode_supported(const GemmArgs &a);
 bool gemm_decode_preferred(const GemmArgs &a);
 DecodeGeom choose_decode_geom(const GemmArgs &a);
