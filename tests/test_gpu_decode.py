@@ -137,10 +137,10 @@ def test_decode_kernel_model_shapes_full_size(ops, name, parts, Kin, T):
     x = torch.randn(T, Kin, device=DEV).to(torch.bfloat16)
     packed = ops.pq_repack_codes(codes, cb, parts)
     name = ops.gemm_kernel_name(T, N, G, 1, 256, 8, 1, x.dtype, parts, packed=True)
-    # the decode kernel where it is the faster one: three chunks or more, or more than 4096 rows; K longer than
-    # 4096 (split over blocks through the workspace a loaded layer has) up to 8 tokens
+    # the decode kernel where it is the faster one: three chunks or more, or more than 4096 rows (K longer than
+    # 4096 is split over blocks through the workspace a loaded layer has)
     ops.ensure_workspace(torch.device(DEV))
-    decode = (Kin // 512 > 2 or N > 4096) if Kin <= 4096 else T <= 8
+    decode = Kin // 512 > 2 or N > 4096
     assert name == ("mfma_decode_packed" if decode else "mfma_stream_packed")
     y = ops.pq_gemm_packed(x, packed, codes, cb, scales, parts, None)
     w = ops.pq_dequant(codes, cb, parts)

@@ -22,14 +22,11 @@ bool gemm_decode_supported(const GemmArgs &a) {
     return choose_decode_geom(a).nf > 0;         // longer K: split over blocks, which needs the workspace
 }
 
-// Measured against the K-split stream kernel on the same launches (tools/decode_ab.py): ahead by 0.1 - 0.6 us wherever
-// a block has at least three chunks or the grid fills the chip; short-K layers of few rows are the stream kernel's.
-// With at most 8 tokens it loads half the activation registers and is ahead by 0.5 - 1.1 us (10 - 20 %), K split over
-// blocks included; a split K at 9..16 tokens is level with the stream kernel's split (within 0.3 us either way) and
-// stays there.
+// Measured against the stream kernel on the same launches (tools/decode_ab.py, profiles/r02_decode_ab.csv): ahead by
+// 0.5 - 2 us (up to 30 %) at 1 .. 16 tokens wherever a block has at least three chunks or the layer more than 4096 rows,
+// K split over blocks included; two-chunk layers of few rows are level and stay with the stream kernel.
 bool gemm_decode_preferred(const GemmArgs &a) {
     if (!gemm_decode_supported(a)) return false;
-    if (a.G / 64 > DC_MAX_WAVES) return a.T <= 8;
     return a.G / 64 > 2 || a.N > 4096;
 }
 
@@ -107,7 +104,6 @@ static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipSt
     p.wk_log2 = g.wk_log2;
     p.img_bytes = (uint32_t)a.K * 256u;
     p.spt = a.K * 16 >= g.waves * 64 ? a.K * 16 / (g.waves * 64) : 1;
-    p.codes_early = 0;
     p.ksplit = g.ksplit;
     p.cpb = g.cpb;
     p.n_total = a.N;
@@ -116,14 +112,14 @@ static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipSt
     const int rows = (g.waves >> g.wk_log2) * g.nf * 16;
     p.tmap = make_tile_map(a.parts, rows);
     const dim3 grid(tiles_in(a.parts, rows), g.ksplit);
-    const size_t lds = (size_t)p.img_bytes + (size_t)g.waves * DC_UMAX * 1024;
+    const size_t lds = dc_lds_bytes(g.waves, p.img_bytes);
     auto launch = [&](auto kern) -> hipError_t {
         static std::atomic<bool> attr_set[64];   // per device: more than the default 64 KiB of LDS
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         if (!attr_set[dev].load(std::memory_order_acquire)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               65536 + DC_STAGE_BYTES);
+                                               (int)dc_lds_bytes(DC_MAX_WAVES, 65536));
             if (e != hipSuccess) return e;
             attr_set[dev].store(true, std::memory_order_release);
         }

@@ -34,6 +34,12 @@ namespace pq {
 constexpr int DC_MAX_WAVES = 8;
 constexpr int DC_UMAX = 8;                       // units of a wave (chunks x fragments): 1 KiB of staging each
 constexpr int DC_STAGE_BYTES = DC_MAX_WAVES * DC_UMAX * 1024;
+constexpr int DC_XROW_BYTES = 1040;               // a token's KiB of a chunk in LDS, padded by one 16-byte slot
+// LDS of a block of `waves` waves with a codebook image of img_bytes: image + staging, or the activation regions
+constexpr size_t dc_lds_bytes(int waves, size_t img_bytes) {
+    const size_t a = img_bytes + (size_t)waves * DC_UMAX * 1024, b = (size_t)waves * 16 * DC_XROW_BYTES;
+    return a > b ? a : b;
+}
 
 struct DecodeParams {
     const unsigned char *x;        // [T][x_stride] act dtype
@@ -51,7 +57,6 @@ struct DecodeParams {
     int wk_log2;                   // log2 of the waves along K
     uint32_t img_bytes;            // K * 256, the staging area follows
     int spt;                       // 16-byte image slots per thread: max(1, K * 16 / threads per block)
-    int codes_early;               // request the code pieces right behind the activations instead of after the barrier
     // K split over blocks (longer K than 8 chunks): block (x, y) takes chunks y * cpb .. + cpb - 1 of tile x; the fp32
     // partial sums [ksplit][T][n_total] meet in the workspace (the streaming kernel's protocol and layout)
     int ksplit;                    // blocks per tile = gridDim.y (1: no split, no workspace)
@@ -87,6 +92,12 @@ __device__ __forceinline__ u32x4 dc_lds_read16(uint32_t addr) {
     asm volatile("; PQX %0\n\tds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
+template <int OFF>
+__device__ __forceinline__ u32x4 dc_lds_read16_at(uint32_t addr) {
+    u32x4 v;
+    asm volatile("; PQX %0\n\tds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
 template <typename V>
 __device__ __forceinline__ void dc_landed(V &v) { asm volatile("; PQL %0" : "+v"(v)); }
 
@@ -114,33 +125,6 @@ __device__ __forceinline__ void dc_wait_vm(int n) {
 }
 #undef DC_VM_ENTRY
 
-// d = lanes in `mask` ? b : (a rotated by 8 lanes within every row of 16): one v_cndmask_b32_dpp per dword
-__device__ __forceinline__ u32x4 dc_sel_ror8(const u32x4 &a, const u32x4 &b, uint64_t mask) {
-    u32x4 d;
-    asm("s_mov_b64 vcc, %12\n\t"
-        "v_cndmask_b32_dpp %0, %4, %8, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32_dpp %1, %5, %9, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32_dpp %2, %6, %10, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32_dpp %3, %7, %11, vcc row_ror:8 row_mask:0xf bank_mask:0xf"
-        : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w)
-        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "s"(mask)
-        : "vcc");
-    return d;
-}
-
-// d = a rotated by 8 lanes within every row of 16
-__device__ __forceinline__ u32x4 dc_ror8(const u32x4 &a) {
-    u32x4 d;
-    asm("v_mov_b32_dpp %0, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp %1, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp %2, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp %3, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
-        : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w)
-        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));
-    return d;
-}
-
-struct DcX { u32x4 f[16]; };   // the activations of one chunk: k-step s of lane (t, q) = x[t][chunk * 512 + 32 s + 8 q .. + 7]
 
 // STAMPS (diagnostic builds only): thread 0 writes wall-clock stamps of the phases to `bias` (8 x u64 per block)
 template <typename AT, bool STAMPS = false>
@@ -166,10 +150,16 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     // A launch of a few microseconds is paced by the instructions its waves issue (a wave issues one every 4-5
     // cycles at best, the two waves of a SIMD share the scalar unit, and code that runs once is fetched at a
     // third of that rate) and by two data streams: the code pieces from HBM, and the activations from L2 --
-    // every block reads all of x, 32 MB of L2 reads for 256 blocks at 16 tokens and K = 4096, about 2 us at the
-    // 55 - 65 GB/s a CU takes in.  The memory pipeline of a CU returns data in request order across all its waves.
-    // So: every wave requests its activations first, the codebook image is stored while they arrive, and the code
-    // pieces (HBM latency) are requested only once every wave of the block has its activation loads queued.
+    // every block reads all of x, 32 MB of L2 reads for 256 blocks at 16 tokens and K = 4096.
+    //
+    // How the activations come in decides the first microseconds.  MFMA k-step s wants lane (q = l >> 4, c = l & 15)
+    // to hold x[token c][32 s + 8 q .. + 7]; a load shaped like that has the four lanes of every quad on four
+    // different rows, and the memory pipeline takes such a wave-load at a quarter of the rate of one whose quads each
+    // read 64 contiguous bytes (measured, tools/ingest_lab.hip: 128 KiB per block in 4.0 us against 1.6).  So a wave
+    // brings its chunk of every token in as ONE contiguous KiB per token, by LDS-DMA, into a padded LDS region of its
+    // own (16 rows of 1040 bytes: the 16 bytes of padding put the 16 tokens of a k-step on different banks), and reads
+    // the 16 operand registers from there (lane (q, c): row c, byte 64 s + 16 q).  The region lies where the codebook
+    // image and the code staging area are built AFTERWARDS: the activations are in registers by then.
     const int WK = 1 << p.wk_log2;
     const int wk = wave & (WK - 1), wr = wave >> p.wk_log2;
     const int nf = p.nf;
@@ -188,7 +178,7 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     DC_STAMP(1)   // tile found
 
     // ---- codebook entries: entry e fills 16 image slots of 16 bytes (one per lane residue); a thread owns spt
-    // consecutive slots
+    // consecutive slots.  Requested first, stored once the activations are out of the LDS.
     int issued = 0;
     const int spt = p.spt;
     const bool img_active = tid * spt < (p.K << 4);
@@ -204,21 +194,27 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     } else {
         ++issued;
     }
-    const int seq_cb = issued - 1;                // sequence number of the last entry load
 
-    // ---- activations and code pieces.  MFMA k-step s wants lane (q = l >> 4, c = l & 15) to hold
-    // x[token c][32 s + 8 q .. + 7]: 16 rows x 64 bytes per wave-load, which the memory pipeline serves far slower than
-    // whole 128-byte lines.  So a pair of loads fetches one line (two k-steps) of tokens 0..7 and of tokens 8..15:
-    // lane (q, c) takes piece q + 4 (c >> 3) of token (c & 7) [+ 8]; the two k-steps' operands are then one
-    // row-local select each (dc_sel_ror8): k-step 2m = lanes c < 8 of the first load | lanes c - 8 of the second,
-    // k-step 2m + 1 the rest.
+    // ---- activations: token t's KiB of the wave's chunk -> row t of the wave's region.  With at most 8 tokens only
+    // 8 rows are brought in (columns 8..15 of the MFMAs then read whatever the LDS holds: those outputs are never
+    // stored, and a column's values do not reach another column).  Tokens past T repeat the last one.
+    const uint32_t xreg = lds0 + (uint32_t)wave * (16u * DC_XROW_BYTES);
+    const unsigned char *xb0 = p.x + (size_t)(chunk0 + (wk < nck_blk ? wk : nck_blk - 1)) * 1024;
+    const int ntok = p.T > 8 ? 16 : 8;
+    {
+        uint32_t xdst = xreg;
+#pragma nounroll
+        for (int t = 0; t < ntok; ++t) {
+            const uint32_t tc = (uint32_t)(t < p.T ? t : p.T - 1);
+            dc_dma16(xdst, lane16, xb0 + (size_t)(tc * p.x_stride_bytes));
+            xdst += DC_XROW_BYTES;
+        }
+    }
+    issued += ntok;
+    DC_STAMP(2)   // entries and activations requested
+
     // Unit i is chunk wk of fragment wr * nf + i of the tile (fragments past the tile's last repeat it and are
     // never stored); its piece goes by DMA straight into staging slot i of the wave.
-    const int xc = lane & 7;
-    const uint32_t xpiece = (uint32_t)((lane >> 4) + 4 * ((lane >> 3) & 1)) * 16u;
-    const uint32_t xoff_a = (uint32_t)(xc < p.T ? xc : p.T - 1) * p.x_stride_bytes + xpiece;
-    const uint32_t xoff_b = (uint32_t)(xc + 8 < p.T ? xc + 8 : p.T - 1) * p.x_stride_bytes + xpiece;
-    const uint64_t lo_lanes = 0x00ff00ff00ff00ffull, hi_lanes = 0xff00ff00ff00ff00ull;
     int fb = wr * nf, nvalid = nfr - fb;           // first fragment of the wave, fragments it really has
     if (nvalid < 1) { fb = nfr - 1; nvalid = 1; }
     const size_t frag_bytes = (size_t)p.nchunks * 1024;
@@ -233,33 +229,43 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
             if (dma_i < nvalid) dma_src += frag_bytes;
         }
     };
-    DcX XA;
-    const unsigned char *xb0 = p.x + (size_t)(chunk0 + (wk < nck_blk ? wk : nck_blk - 1)) * 1024;
-    // With at most 8 tokens the second load of every pair (tokens 8..15) is left out: the memory pipeline takes a
-    // wave-load of 1 KiB every 36-40 cycles whatever it holds, and these 8 of a wave's 16 are a microsecond per block.
-    const bool two = p.T > 8;
-#define DC_XA(m) XA.f[2 * (m)] = dc_gload16<128 * (m)>(xoff_a, xb0);
-#define DC_XB(m) XA.f[2 * (m) + 1] = dc_gload16<128 * (m)>(xoff_b, xb0);
-    DC_XA(0) DC_XA(1) DC_XA(2) DC_XA(3) DC_XA(4) DC_XA(5) DC_XA(6) DC_XA(7)
-    if (two) {
-        DC_XB(0) DC_XB(1) DC_XB(2) DC_XB(3) DC_XB(4) DC_XB(5) DC_XB(6) DC_XB(7)
-    }
-#undef DC_XA
-#undef DC_XB
-    issued += two ? 16 : 8;
-    const int seq_xa = issued - 1;                // sequence number of the set's last load
-    int seq_dma0 = issued;
-    if (p.codes_early) {
-#pragma nounroll
-        for (int j = 0; j < U; ++j) issue_dma(j);
-        issued += U;
-    }
-    DC_STAMP(2)   // entries and activations requested
 
-    // ---- codebook image, stored while the memory pipeline works through the activation loads
-    dc_wait_vm(issued - 1 - seq_cb);               // the entries are the oldest requests
+    // ---- the activations have landed (and so have the codebook entries, which are older): operand registers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dc_landed(cbv0);
-    DC_STAMP(3)   // entries landed
+    issued = 0;
+    DC_STAMP(3)   // entries and activations landed
+    u32x4 B0[16];
+    {
+        const uint32_t xrd = xreg + (uint32_t)(lane & 15) * DC_XROW_BYTES + (uint32_t)(lane >> 4) * 16u;
+#define DC_XR(s) B0[s] = dc_lds_read16_at<64 * (s)>(xrd);
+        DC_XR(0) DC_XR(1) DC_XR(2) DC_XR(3) DC_XR(4) DC_XR(5) DC_XR(6) DC_XR(7)
+        DC_XR(8) DC_XR(9) DC_XR(10) DC_XR(11) DC_XR(12) DC_XR(13) DC_XR(14) DC_XR(15)
+#undef DC_XR
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define DC_XD(s) dc_landed(B0[s]);
+        DC_XD(0) DC_XD(1) DC_XD(2) DC_XD(3) DC_XD(4) DC_XD(5) DC_XD(6) DC_XD(7)
+        DC_XD(8) DC_XD(9) DC_XD(10) DC_XD(11) DC_XD(12) DC_XD(13) DC_XD(14) DC_XD(15)
+#undef DC_XD
+    }
+    DC_STAMP(4)   // operands in registers
+    __syncthreads();   // every wave has its activations out of the LDS: image and staging may be written
+    DC_STAMP(5)   // barrier
+
+    // ---- code pieces (HBM: the longest latency, requested first), epilogue operands, codebook image
+    const int seq_dma0 = issued;
+#pragma nounroll
+    for (int j = 0; j < U; ++j) issue_dma(j);
+    issued += U;
+    // wave (wk, wr) with wk < nf finishes fragment wk of row group wr: token lane & 15, rows 4 (lane >> 4) .. + 3
+    const int out_frag = wr * nf + wk;
+    const bool out_wave = wk < nf && out_frag < nfr;
+    const int out_row = loc.row0 + (out_wave ? out_frag : 0) * 16 + (lane >> 4) * 4;
+    u32x2 scv = dc_gload8((uint32_t)out_row * 2u, p.scales);
+    ++issued;
+    u32x2 biv = dc_gload8((uint32_t)out_row * 2u, bias ? bias : p.scales);   // without a bias: loaded, never used
+    ++issued;
+    DC_STAMP(6)   // everything requested
     if (img_active) {
         if (spt == 8) {
             // 256 entries, 512 threads: the thread's 8 slots, in an order permuted per lane (slot c ^ (tid & 7)) so
@@ -292,52 +298,8 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
         for (int i = 0; i < nf; ++i)
             *reinterpret_cast<f32x4 *>(smem + p.img_bytes + ((size_t)(wave * DC_UMAX + i) * 64 + lane) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    DC_STAMP(4)   // image stored
-    // One barrier does two things: the image is complete, and every wave of the block has requested its
-    // activations -- a code piece (HBM) requested before that would hold the activations of the slower waves back by
-    // an HBM latency (returns are in request order across the waves of a CU).
-    __syncthreads();
-    DC_STAMP(5)   // barrier
-
-    // ---- code pieces, epilogue operands
-    if (!p.codes_early) {
-        seq_dma0 = issued;
-#pragma nounroll
-        for (int j = 0; j < U; ++j) issue_dma(j);
-        issued += U;
-    }
-    // wave (wk, wr) with wk < nf finishes fragment wk of row group wr: token lane & 15, rows 4 (lane >> 4) .. + 3
-    const int out_frag = wr * nf + wk;
-    const bool out_wave = wk < nf && out_frag < nfr;
-    const int out_row = loc.row0 + (out_wave ? out_frag : 0) * 16 + (lane >> 4) * 4;
-    u32x2 scv = dc_gload8((uint32_t)out_row * 2u, p.scales);
-    ++issued;
-    u32x2 biv = dc_gload8((uint32_t)out_row * 2u, bias ? bias : p.scales);   // without a bias: loaded, never used
-    ++issued;
-    DC_STAMP(6)   // everything requested
-
-    // the first chunk's activations: wait, and permute them into the MFMA operands of its 16 k-steps
-    auto prepare = [&](DcX &X, int seq_x, u32x4 (&B)[16]) {
-        dc_wait_vm(issued - 1 - seq_x);
-#define DC_XD(s) dc_landed(X.f[s]);
-        DC_XD(0) DC_XD(2) DC_XD(4) DC_XD(6) DC_XD(8) DC_XD(10) DC_XD(12) DC_XD(14)
-        if (two) {
-            DC_XD(1) DC_XD(3) DC_XD(5) DC_XD(7) DC_XD(9) DC_XD(11) DC_XD(13) DC_XD(15)
-#define DC_XF(m) B[2 * (m)] = dc_sel_ror8(X.f[2 * (m) + 1], X.f[2 * (m)], lo_lanes); B[2 * (m) + 1] = dc_sel_ror8(X.f[2 * (m)], X.f[2 * (m) + 1], hi_lanes);
-            DC_XF(0) DC_XF(1) DC_XF(2) DC_XF(3) DC_XF(4) DC_XF(5) DC_XF(6) DC_XF(7)
-#undef DC_XF
-        } else {
-            // tokens 0..7 only: the loaded register is k-step 2m as it is (lanes of tokens 8..15 hold other finite
-            // activations; their output columns are never stored), k-step 2m + 1 is the same register rotated
-#define DC_XF(m) B[2 * (m)] = X.f[2 * (m)]; B[2 * (m) + 1] = dc_ror8(X.f[2 * (m)]);
-            DC_XF(0) DC_XF(1) DC_XF(2) DC_XF(3) DC_XF(4) DC_XF(5) DC_XF(6) DC_XF(7)
-#undef DC_XF
-        }
-#undef DC_XD
-    };
-    u32x4 B0[16];
-    prepare(XA, seq_xa, B0);
-    DC_STAMP(7)   // activations landed and permuted
+    __syncthreads();   // the image is complete
+    DC_STAMP(7)   // image stored, barrier
 
     // ---- units ------------------------------------------------------------------------------------------------------
     const uint32_t img_lane = lds0 + (uint32_t)(lane & 15) * 16u;   // this lane's copy of entry 0
