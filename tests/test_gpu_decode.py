@@ -73,6 +73,18 @@ def test_decode_kernel_k_split_over_blocks(ops, monkeypatch, Kin, cfg, T):
     assert_close_to_exact(bits_of(y), y32, "bf16", f"decode K split Kin={Kin} cfg={cfg} T={T}")
 
 
+# more than 16 tokens: groups of 16 over the grid, every group with its own rows of y and of the K-split partials
+@pytest.mark.parametrize("Kin,cfg", [(1024, None), (4096, None), (4096, "8x3"), (8192, None), (14336, "8x2")])
+@pytest.mark.parametrize("T", [17, 32, 100, 128])
+def test_decode_kernel_token_groups(ops, monkeypatch, Kin, cfg, T):
+    parts = [208, 112, 16]
+    ops.ensure_workspace(torch.device(DEV))
+    p = Problem(3000 + Kin // 512 + T, 256, 8, 1, parts, Kin, T, "bf16", bias=(T != 32)).to(DEV)
+    y = _run(ops, monkeypatch, p, parts, cfg)
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(y), y32, "bf16", f"decode token groups Kin={Kin} cfg={cfg} T={T}")
+
+
 def test_decode_kernel_long_k_without_workspace_is_the_stream_kernels(ops):
     """Without a workspace a K of more than 4096 cannot be split over blocks: the library says so through the
     kernel it names for a launch that has none, and still computes the layer."""

@@ -95,6 +95,12 @@ def main():
                     t = time_call(fn, use)
                     if t is not None:
                         cands[f"stream {cfg} ks{ks}"] = t
+            if T <= 128 and K <= 256 and d == 8:
+                set_env(PQ_AMD_FORCE_KERNEL="decode")
+                if ops.gemm_kernel_name(T, N, G, 1, K, d, cbytes, dt, parts, packed=True) == "mfma_decode_packed":
+                    t = time_call(fn, use)
+                    if t is not None:
+                        cands["decode"] = t
             if T > 16:
                 for i in range(7):
                     set_env(PQ_AMD_FORCE_KERNEL="tiled", PQ_AMD_TILED_CFG=i)

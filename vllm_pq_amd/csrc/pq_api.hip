@@ -72,8 +72,8 @@ Kernel choose(const pq::GemmArgs &a) {
         // Mid-size batches.  The tiled kernel does not split K, so below 256 output tiles of 64 x 64 it
         // cannot fill the 256 CUs and one launch lasts about 3 us + 3 us per 1024 input features (one
         // 64 x 64 tile per CU, measured: the HBM latency of the code loads paces the short steps); the
-        // streaming kernel splits K over its waves and wins there whenever its own modelled duration is
-        // shorter.
+        // streaming kernel splits K over its waves, the decode kernel runs the batch as groups of 16 tokens:
+        // whichever has the shortest modelled duration.
         const double out_tiles = (double)a.T * a.N / 4096.0;
         if (out_tiles <= 256.0) {
             double stream_us = 0.0;
@@ -83,6 +83,9 @@ Kernel choose(const pq::GemmArgs &a) {
             // codebook image: measured 1.15x ... 2.6x the time of d = 8 with one-byte codes
             const double fmt = sqrt(8.0 / a.d) * (a.code_bytes == 2 ? 1.3 : 1.0);
             const double tiled_us = (double)((tiles64 + 255) / 256) * (3.0 + 3.0 * (double)a.G * a.d / 1024.0) * fmt;
+            const double decode_us = (force < 0 && pq::gemm_decode_supported(a)) ? pq::decode_model_us(a) : 0.0;
+            const double other_us = (stream_us > 0.0 && stream_us <= tiled_us) ? stream_us : tiled_us;
+            if (decode_us > 0.0 && decode_us < other_us) return K_DECODE;
             if (stream_us > 0.0 && stream_us <= tiled_us) return K_STREAM;
         }
         return K_TILED;

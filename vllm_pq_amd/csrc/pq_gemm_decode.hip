@@ -9,7 +9,7 @@ namespace pq {
 bool gemm_decode_supported(const GemmArgs &a) {
     if (!a.packed || a.d != 8 || a.M != 1 || a.code_bytes != 1) return false;
     if (a.K < 16 || a.K > 256 || (a.K & (a.K - 1))) return false;
-    if (a.T < 1 || a.T > 16 || a.G < 64 || a.G % 64) return false;          // whole 512-feature chunks
+    if (a.T < 1 || a.T > DC_MAX_TOKENS || a.G < 64 || a.G % 64) return false;          // whole 512-feature chunks
     if (a.x_stride % 8 || (uint64_t)a.x_stride * 2 * 16 >= (1ull << 31)) return false;
     if (a.N <= 0 || (int64_t)a.N * 2 >= (1ll << 31)) return false;
     if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.codes) | reinterpret_cast<uintptr_t>(a.codebooks)) & 15)
@@ -27,7 +27,20 @@ bool gemm_decode_supported(const GemmArgs &a) {
 // K split over blocks included; two-chunk layers of few rows are level and stay with the stream kernel.
 bool gemm_decode_preferred(const GemmArgs &a) {
     if (!gemm_decode_supported(a)) return false;
+    if (a.T > 16) return false;                  // token groups: chosen by the caller's comparison of modelled durations
     return a.G / 64 > 2 || a.N > 4096;
+}
+
+// Modelled duration in microseconds of the launch choose_decode_geom() picks, for the comparison with the other
+// kernels at 17 .. DC_MAX_TOKENS tokens (every group of 16 tokens gathers the weights again, so this kernel is for
+// layers whose blocks hold few units): measured 5.0 us for a one-unit block at 4096 inputs, 0.45 us per further unit
+// of a wave, 2 us for the hand-over of a K split.
+double decode_model_us(const GemmArgs &a) {
+    const DecodeGeom g = choose_decode_geom(a);
+    if (g.nf == 0) return 0.0;
+    const long blocks = (long)tiles_in(a.parts, (g.waves >> g.wk_log2) * g.nf * 16) * g.ksplit * ((a.T + 15) / 16);
+    const double rounds = (double)((blocks + 255) / 256);
+    return rounds * (3.2 + 0.22 * g.cpb + 0.45 * g.nf) + (g.ksplit > 1 ? 2.0 : 0.0);
 }
 
 // Blocks per tile for K longer than a block's 8 chunks: the fewest that cover K with at most 8 chunks each and,
@@ -43,7 +56,7 @@ static int decode_ksplit(const GemmArgs &a, int nchunks) {
 }
 
 size_t decode_workspace_bytes(int T, int N, int G, int M, int K, int d, int code_bytes) {
-    if (d != 8 || M != 1 || code_bytes != 1 || K < 16 || K > 256 || T < 1 || T > 16 || G % 64) return 0;
+    if (d != 8 || M != 1 || code_bytes != 1 || K < 16 || K > 256 || T < 1 || T > DC_MAX_TOKENS || G % 64) return 0;
     const int nchunks = G / 64;
     if (nchunks <= DC_MAX_WAVES || nchunks > 8 * DC_MAX_WAVES) return 0;
     const size_t part = (size_t)((nchunks + DC_MAX_WAVES - 1) / DC_MAX_WAVES) * T * N * 4;
@@ -75,8 +88,9 @@ DecodeGeom choose_decode_geom(const GemmArgs &a) {
     }
     for (int wr = 1; wr * WK <= DC_MAX_WAVES; wr *= 2) {
         for (int nf = 1; nf <= WK && nf * g.c <= DC_UMAX; ++nf) {
-            const long tiles = (long)tiles_in(a.parts, wr * nf * 16) * g.ksplit;
-            if (g.ksplit > 1 && tiles / g.ksplit * 4 > (long)WS_COUNTER_BYTES) continue;   // one counter per tile
+            const int tgroups = (a.T + 15) / 16;
+            const long tiles = (long)tiles_in(a.parts, wr * nf * 16) * g.ksplit * tgroups;
+            if (g.ksplit > 1 && tiles / g.ksplit * 4 > (long)WS_COUNTER_BYTES) continue;   // one counter per tile and token group
             const double rounds = (double)((tiles + 255) / 256);
             // fixed: launch ramp, image, epilogue; per unit of a wave about 0.3 us; blocks of few waves share a CU
             const double cost = rounds * (3.0 + 0.3 * nf * g.c) + (tiles < 256 ? 0.002 * (256 - tiles) : 0.0) * nf * g.c;
@@ -111,7 +125,7 @@ static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipSt
     p.ws_part = g.ksplit > 1 ? reinterpret_cast<float *>(static_cast<unsigned char *>(a.workspace) + WS_COUNTER_BYTES) : nullptr;
     const int rows = (g.waves >> g.wk_log2) * g.nf * 16;
     p.tmap = make_tile_map(a.parts, rows);
-    const dim3 grid(tiles_in(a.parts, rows), g.ksplit);
+    const dim3 grid(tiles_in(a.parts, rows), g.ksplit, (a.T + 15) / 16);
     const size_t lds = dc_lds_bytes(g.waves, p.img_bytes);
     auto launch = [&](auto kern) -> hipError_t {
         static std::atomic<bool> attr_set[64];   // per device: more than the default 64 KiB of LDS

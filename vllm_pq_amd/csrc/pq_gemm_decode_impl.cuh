@@ -32,6 +32,7 @@
 namespace pq {
 
 constexpr int DC_MAX_WAVES = 8;
+constexpr int DC_MAX_TOKENS = 128;                // batches beyond 16 tokens run as groups of 16 over gridDim.z
 constexpr int DC_UMAX = 8;                       // units of a wave (chunks x fragments): 1 KiB of staging each
 constexpr int DC_STAGE_BYTES = DC_MAX_WAVES * DC_UMAX * 1024;
 constexpr int DC_XROW_BYTES = 1040;               // a token's KiB of a chunk in LDS, padded by one 16-byte slot
@@ -50,7 +51,7 @@ struct DecodeParams {
     uint16_t *y;
     int64_t y_stride;              // elements
     uint32_t x_stride_bytes;
-    int T;
+    int T;                         // tokens of the batch (16 per block: gridDim.z groups)
     int nchunks;                   // 512-feature chunks of K (at most 1 << wk_log2)
     int K;                         // codebook entries (power of two, 16 .. 256)
     int nf;                        // fragments per wave
@@ -136,6 +137,9 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint16_t *bias = p.bias;
+    // batches of more than 16 tokens: block z takes tokens 16 z .. 16 z + 15 (every group gathers the weights again)
+    const int tok0 = (int)blockIdx.z * 16;
+    const int T = p.T - tok0 < 16 ? p.T - tok0 : 16;          // tokens of this block
     // STAMPS: the first and the last wave keep 12 wall-clock stamps each in registers and store them at the very end
     // (24 x u64 per block behind `bias`): a store in between would sit in the memory pipeline with the loads
     unsigned long long st[12];
@@ -199,13 +203,13 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     // 8 rows are brought in (columns 8..15 of the MFMAs then read whatever the LDS holds: those outputs are never
     // stored, and a column's values do not reach another column).  Tokens past T repeat the last one.
     const uint32_t xreg = lds0 + (uint32_t)wave * (16u * DC_XROW_BYTES);
-    const unsigned char *xb0 = p.x + (size_t)(chunk0 + (wk < nck_blk ? wk : nck_blk - 1)) * 1024;
-    const int ntok = p.T > 8 ? 16 : 8;
+    const unsigned char *xb0 = p.x + (size_t)tok0 * p.x_stride_bytes + (size_t)(chunk0 + (wk < nck_blk ? wk : nck_blk - 1)) * 1024;
+    const int ntok = T > 8 ? 16 : 8;
     {
         uint32_t xdst = xreg;
 #pragma nounroll
         for (int t = 0; t < ntok; ++t) {
-            const uint32_t tc = (uint32_t)(t < p.T ? t : p.T - 1);
+            const uint32_t tc = (uint32_t)(t < T ? t : T - 1);
             dc_dma16(xdst, lane16, xb0 + (size_t)(tc * p.x_stride_bytes));
             xdst += DC_XROW_BYTES;
         }
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
         u32x2 o2;
         o2.x = h[0] | ((uint32_t)h[1] << 16);
         o2.y = h[2] | ((uint32_t)h[3] << 16);
-        *reinterpret_cast<u32x2 *>(p.y + (size_t)t_out * p.y_stride + out_row) = o2;
+        *reinterpret_cast<u32x2 *>(p.y + (size_t)(tok0 + t_out) * p.y_stride + out_row) = o2;
     };
     if (out_wave) {
         const unsigned char *slot = smem + p.img_bytes + ((size_t)((wr << p.wk_log2) * DC_UMAX + wk) * 64 + lane) * 16;
@@ -386,9 +390,9 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
             const f32x4 v = *reinterpret_cast<const f32x4 *>(slot + (size_t)w * (DC_UMAX * 1024));
             sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
         }
-        if (t_out < p.T) {
+        if (t_out < T) {
             if (p.ksplit == 1) finish(sum);
-            else coherent_store16(p.ws_part + ((size_t)blockIdx.y * p.T + t_out) * (size_t)p.n_total + out_row, sum);
+            else coherent_store16(p.ws_part + ((size_t)blockIdx.y * p.T + tok0 + t_out) * (size_t)p.n_total + out_row, sum);
         }
     }
     // K split over blocks: every block counts itself in on its tile's counter; the last one to arrive adds the partial
@@ -402,18 +406,18 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            unsigned *cnt = p.ws_cnt + blockIdx.x;
+            unsigned *cnt = p.ws_cnt + blockIdx.z * gridDim.x + blockIdx.x;
             const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = old == (unsigned)p.ksplit - 1u;
             if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (s_last && out_wave && t_out < p.T) {
+        if (s_last && out_wave && t_out < T) {
             f32x4 part[8];   // all requested before any is waited for; splits past the last re-read the last one
 #pragma unroll
             for (int z = 0; z < 8; ++z) {
                 const int zc = z < p.ksplit ? z : p.ksplit - 1;
-                part[z] = coherent_load16_issue(p.ws_part + ((size_t)zc * p.T + t_out) * (size_t)p.n_total + out_row);
+                part[z] = coherent_load16_issue(p.ws_part + ((size_t)zc * p.T + tok0 + t_out) * (size_t)p.n_total + out_row);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
         const int nw = (int)(blockDim.x >> 6);
         if (lane == 0 && (wave == 0 || wave == nw - 1)) {
             unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<uint16_t *>(p.bias)) +
-                                    ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 24 + (wave == 0 ? 0 : 12);
+                                    (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 24 + (wave == 0 ? 0 : 12);
 #pragma unroll
             for (int k = 0; k < 12; ++k) o[k] = st[k];
         }

@@ -65,7 +65,7 @@ bool gemm_stream_act_supported(const GemmArgs &a);
 int choose_stream_act_nf(const GemmArgs &a);
 hipError_t launch_gemm_stream_act(const GemmArgs &a, hipStream_t stream);
 
-// Decode batches (at most 16 tokens; d = 8, one codebook of up to 256 entries, one-byte packed codes, whole
+// Decode batches (16 tokens per block, up to 128 as groups over the grid; d = 8, one codebook of up to 256 entries, one-byte packed codes, whole
 // 512-feature chunks): pq_gemm_decode_impl.cuh.  `waves` per block, of which 1 << wk_log2 along K; nf fragments
 // and c chunks per wave.  nf == 0: not taken.
 struct DecodeGeom { int nf, wk_log2, c, waves, ksplit, cpb; };   // ksplit blocks per tile along K, cpb chunks each
@@ -74,6 +74,7 @@ struct DecodeGeom { int nf, wk_log2, c, waves, ksplit, cpb; };   // ksplit block
 size_t decode_workspace_bytes(int T, int N, int G, int M, int K, int d, int code_bytes);
 bool gemm_decode_supported(const GemmArgs &a);
 bool gemm_decode_preferred(const GemmArgs &a);
+double decode_model_us(const GemmArgs &a);   // modelled launch duration (0: not taken), for batches beyond 16 tokens
 DecodeGeom choose_decode_geom(const GemmArgs &a);
 hipError_t launch_gemm_decode(const GemmArgs &a, hipStream_t stream);
 
