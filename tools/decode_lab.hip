@@ -20,7 +20,8 @@ const Knobs &knobs() { static Knobs k{-1, 0, 0, 0, -1, 0, 0, 0}; return k; }
 
 struct Shape { const char *name; int nparts; int parts[3]; int Kin; };
 
-static void run(const Shape &sh, int T, int waves_force, int nf_force, bool stamps, int codes_first = 0) {
+template <int ABL = 0>
+static void run(const Shape &sh, int T, int waves_force, int nf_force, bool stamps) {
     const int K = 256;
     int N = 0;
     GemmArgs a;
@@ -60,10 +61,11 @@ static void run(const Shape &sh, int T, int waves_force, int nf_force, bool stam
         p.codes = (const unsigned char *)pk[i % copies];
         p.bias = stamped ? (const uint16_t *)st : nullptr;
         if (stamped) hipLaunchKernelGGL((gemm_decode_kernel<bf16_t, true>), dim3(ntile, g.ksplit), dim3(g.waves * 64), lds, 0, p);
-        else hipLaunchKernelGGL((gemm_decode_kernel<bf16_t, false>), dim3(ntile, g.ksplit), dim3(g.waves * 64), lds, 0, p);
+        else hipLaunchKernelGGL((gemm_decode_kernel<bf16_t, false, ABL>), dim3(ntile, g.ksplit), dim3(g.waves * 64), lds, 0, p);
     };
     static bool attr = false;
     if (!attr) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_decode_kernel<bf16_t, false, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dc_lds_bytes(DC_MAX_WAVES, 65536)));
         CK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_decode_kernel<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dc_lds_bytes(DC_MAX_WAVES, 65536)));
         CK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_decode_kernel<bf16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dc_lds_bytes(DC_MAX_WAVES, 65536)));
         attr = true;
@@ -82,7 +84,7 @@ static void run(const Shape &sh, int T, int waves_force, int nf_force, bool stam
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / nrep;
     const double bytes = (double)N * G + (double)sh.nparts * K * 16 + N * 2.0 + (double)T * sh.Kin * 2 + (double)T * N * 2;
-    printf("%-16s%s T=%2d N=%5d Kin=%5d waves=%d wk=%d nf=%d c=%d blocks=%4d: %6.2f us/launch  %6.0f GB/s  (%.3f of 8 TB/s)\n", sh.name, codes_first ? " [codes early]" : "", T, N,
+    printf("%-16s%s T=%2d N=%5d Kin=%5d waves=%d wk=%d nf=%d c=%d blocks=%4d: %6.2f us/launch  %6.0f GB/s  (%.3f of 8 TB/s)\n", sh.name, ABL == 0 ? "" : ABL == 1 ? " [no MFMA]" : ABL == 2 ? " [no gathers]" : " [neither]", T, N,
            sh.Kin, g.waves, 1 << g.wk_log2, g.nf, g.c, nblk, us, bytes / us * 1e-3, bytes / us * 1e-3 / 8000.0);
     if (stamps) {
         for (int i = 0; i < 4; ++i) { launch(i, true); CK(hipDeviceSynchronize()); }
@@ -117,6 +119,9 @@ int main(int argc, char **argv) {
     run(shapes[2], 1, 0, 0, stamps);
     for (const Shape &sh : shapes) run(sh, 8, 0, 0, false);
     run(shapes[1], 1, 0, 0, stamps);
+    printf("---- ablations (wrong results): gate_up and down_proj at 16 tokens without the MFMAs / the gathers / both ----\n");
+    run<1>(shapes[2], 16, 0, 0, false); run<2>(shapes[2], 16, 0, 0, false); run<3>(shapes[2], 16, 0, 0, false);
+    run<1>(shapes[3], 16, 0, 0, false); run<2>(shapes[3], 16, 0, 0, false); run<3>(shapes[3], 16, 0, 0, false);
     // alternatives for the big ones
     run(shapes[2], 16, 8, 8, false);
     run(shapes[0], 16, 8, 1, false);

@@ -128,7 +128,8 @@ __device__ __forceinline__ void dc_wait_vm(int n) {
 
 
 // STAMPS (diagnostic builds only): thread 0 writes wall-clock stamps of the phases to `bias` (8 x u64 per block)
-template <typename AT, bool STAMPS = false>
+// ABL (diagnostic builds only; 0 in the library): bit 0 leaves the MFMAs of the units out, bit 1 the gathers
+template <typename AT, bool STAMPS = false, int ABL = 0>
 __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const DecodeParams p) {
     typedef typename Act<AT>::vec8 vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -318,14 +319,16 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
         u32x4 cw = dc_lds_read16(stage0 + lane16);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         dc_landed(cw);
-#define DC_G(A, j, s, sel) A[j] = dc_lds_read16(__builtin_amdgcn_perm(cw[(s) >> 2], img_lane, sel));
+#define DC_G(A, j, s, sel) if constexpr (ABL & 2) { A[j] = cw; asm volatile("; PQX %0" : "+v"(A[j])); } else A[j] = dc_lds_read16(__builtin_amdgcn_perm(cw[(s) >> 2], img_lane, sel));
 #define DC_GLO DC_G(a0, 0, 0, sel0) DC_G(a0, 1, 1, sel1) DC_G(a0, 2, 2, sel2) DC_G(a0, 3, 3, sel3) DC_G(a0, 4, 4, sel0) DC_G(a0, 5, 5, sel1) DC_G(a0, 6, 6, sel2) DC_G(a0, 7, 7, sel3)
 #define DC_GHI DC_G(a1, 0, 8, sel0) DC_G(a1, 1, 9, sel1) DC_G(a1, 2, 10, sel2) DC_G(a1, 3, 11, sel3) DC_G(a1, 4, 12, sel0) DC_G(a1, 5, 13, sel1) DC_G(a1, 6, 14, sel2) DC_G(a1, 7, 15, sel3)
 #define DC_MW(j, s, n)                                                                    \
     asm volatile("s_waitcnt lgkmcnt(%1)\n\t; PQL %0" : "+v"(a0[j]) : "n"(n));               \
+    if constexpr (ABL & 1) acc.x += __uint_as_float(a0[j].x ^ B[s].x); else                \
     acc = Act<AT>::mfma16(__builtin_bit_cast(vec8, a0[j]), __builtin_bit_cast(vec8, B[s]), acc); \
     __builtin_amdgcn_sched_barrier(0);
 #define DC_MN(j, s)                                                                       \
+    if constexpr (ABL & 1) acc.x += __uint_as_float(a1[j].x ^ B[s].x); else                \
     acc = Act<AT>::mfma16(__builtin_bit_cast(vec8, a1[j]), __builtin_bit_cast(vec8, B[s]), acc); \
     __builtin_amdgcn_sched_barrier(0);
         DC_GLO
