@@ -149,8 +149,10 @@ def test_gemm_packed_equals_reference_layout(ops, K, d, M, parts, Kin, T, dtype,
         return
     assert packed is not None and packed.dtype == torch.uint8
     pname = ops.gemm_kernel_name(T, p.N, p.G, M, K, d, p.codes.element_size(), p.x.dtype, parts, packed=True)
-    # the tiled kernel takes T > 16 when in_features is a whole number of its code pieces
-    assert pname in (("mfma_tiled_packed", "mfma_stream_packed") if T > 16 else ("mfma_stream_packed", "mfma_decode_packed"))
+    # the tiled kernel takes T > 16 when in_features is a whole number of its code pieces; the decode kernel takes
+    # batches of up to 128 tokens (as groups of 16) where its modelled launch is the shortest
+    assert pname in (("mfma_tiled_packed", "mfma_stream_packed", "mfma_decode_packed") if T > 16
+                     else ("mfma_stream_packed", "mfma_decode_packed"))
     y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
     _, y32 = p.oracle_gemm(order=2)
     assert_close_to_exact(bits_of(y), y32, dtype)

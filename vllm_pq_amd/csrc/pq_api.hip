@@ -81,7 +81,8 @@ Kernel choose(const pq::GemmArgs &a) {
             const long tiles64 = (long)((a.N + 63) / 64) * ((a.T + 63) / 64);
             // sub-vectors shorter than 8 take 8/d gathers per operand and two-byte codes a less replicated
             // codebook image: measured 1.15x ... 2.6x the time of d = 8 with one-byte codes
-            const double fmt = sqrt(8.0 / a.d) * (a.code_bytes == 2 ? 1.3 : 1.0);
+            // (d = 2 with two-byte codes: four gathers per operand from an image with one copy per entry, 4x)
+            const double fmt = (a.d == 2 && a.code_bytes == 2) ? 4.0 : sqrt(8.0 / a.d) * (a.code_bytes == 2 ? 1.3 : 1.0);
             const double tiled_us = (double)((tiles64 + 255) / 256) * (3.0 + 3.0 * (double)a.G * a.d / 1024.0) * fmt;
             const double decode_us = (force < 0 && pq::gemm_decode_supported(a)) ? pq::decode_model_us(a) : 0.0;
             const double other_us = (stream_us > 0.0 && stream_us <= tiled_us) ? stream_us : tiled_us;

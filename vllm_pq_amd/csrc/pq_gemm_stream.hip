@@ -163,7 +163,8 @@ StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {
             if (nf > 2 && !light) continue;
             if (nf > 4 && !packed) continue;
             for (int want = 1; want <= smax; want *= 2) {
-                if (forced ? want != 1 : (want > 1 && a.T < 4)) continue;
+                // (below 4 tokens a split pays only where a chunk is short: formats with 64 features per chunk)
+                if (forced ? want != 1 : (want > 1 && a.T < 4 && chunk_groups(a.code_bytes, a.M) * a.d > 64)) continue;
                 const int ks = split_for(nf, 1, forced ? forced : want);
                 const double cost = stream_tall_model_us(a, nf, ks);
                 if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = StreamCfg{nf, 1, ks}; }
@@ -188,8 +189,12 @@ StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {
     // ... or one token fragment per block and the batch spread over grid.y: every block then loads only 16
     // tokens of x (a wide block's waves spend most of their time loading theirs), at the price of gathering
     // each weight fragment once per 16 tokens.  Pays while the whole grid still fits the chip in one round.
+    // (the formats with several gathers per operand gather too much per token that way beyond 64 tokens -- d = 2
+    // with two-byte codes beyond 32: measured, tools/autotune.py --square)
+    const bool no_tall = !light && (a.T > 64 || (a.T > 32 && a.d == 2 && a.code_bytes == 2));
     static const int tall[] = {8, 7, 4, 2, 1};
     for (int nf : tall) {
+        if (no_tall) break;
         if (nf > 2 && !light) continue;
         for (int want = 1; want <= smax; want *= 2) {
             if (forced && want != 1) continue;
