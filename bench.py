@@ -362,22 +362,96 @@ def layer_chain(stack, T, device, dtype, cfg=LLAMA3_8B, reps=5):
             h, _ = blk["down_proj"](a)
         return h
 
-    step()
-    torch.cuda.synchronize()
-    g = Graph(step)
-    g.replay()
-    torch.cuda.synchronize()
-    best = 1e9
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        g.replay()
-        e1.record()
+    # The same chain with every add + norm carried by the linears either side of it (PQLinearMethod.apply_add_norm /
+    # apply_normed: decode batches, one rank): o_proj -> [add, norm] -> gate_up_proj, down_proj -> [add, norm] -> the
+    # next layer's qkv_proj; the first layer's input norm and the activation stay launches of their own.
+    qm = stack[0]["o_proj"].quant_method
+    fusable = all(qm.norm_pair_supported(b["o_proj"], b["gate_up_proj"], T) and
+                  qm.norm_pair_supported(b["down_proj"], b["qkv_proj"], T) for b in stack[:1])
+
+    def step_fused():
+        from vllm_pq_amd import ops
+        h, res = x0.clone(), x0.clone()
+        h, res = norms[0][0](h, res)
+        qkv, _ = stack[0]["qkv_proj"](h)
+        for i, (blk, (n1, n2)) in enumerate(zip(stack, norms)):
+            xw, ssq = qm.apply_add_norm(blk["o_proj"], qkv[:, :q], res, n2.weight.data)
+            gu = qm.apply_normed(blk["gate_up_proj"], xw, ssq, 1e-5)
+            a = torch.empty(gu.shape[:-1] + (gu.shape[-1] // 2,), dtype=gu.dtype, device=gu.device)
+            ops.silu_and_mul(a, gu)
+            if i + 1 < len(stack):
+                xw, ssq = qm.apply_add_norm(blk["down_proj"], a, res, norms[i + 1][0].weight.data)
+                qkv = qm.apply_normed(stack[i + 1]["qkv_proj"], xw, ssq, 1e-5)
+            else:
+                h, _ = blk["down_proj"](a)
+        return h
+
+    def timed(fn):
+        fn()
         torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1))
+        g = Graph(fn)
+        g.replay()
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best
+
+    separate = timed(step)
+    if fusable:
+        fused = timed(step_fused)
+        return {"ms": fused, "ms_separate_norms": separate, "layers": len(stack), "launch": "hipgraph",
+                "steps_per_layer": ["o_proj+add (+ sum of squares)", "gate_up_proj (x 1/rms)", "silu_and_mul",
+                                    "down_proj+add (+ sum of squares)", "next qkv_proj (x 1/rms)"],
+                "steps_per_layer_separate": ["fused_add_rms_norm", "qkv_proj", "o_proj", "fused_add_rms_norm",
+                                             "gate_up_proj+silu_and_mul", "down_proj"]}
+    best = separate
     return {"ms": best, "layers": len(stack), "steps_per_layer": ["fused_add_rms_norm", "qkv_proj", "o_proj",
                                                                  "fused_add_rms_norm", "gate_up_proj+silu_and_mul",
                                                                  "down_proj"], "launch": "hipgraph"}
+
+
+def mfma_ceiling(device, dtype, seconds=1.5):
+    """What a bare MFMA loop reaches on THIS device with operands drawn like the benchmark's (normal values rounded
+    to the act dtype, in registers, no memory traffic; tools/pq_probe.hip): the chip lowers its clock under MFMA load
+    by an amount that depends on the operands' bit patterns, so the nominal peak is not attainable on such data.
+    None when the probe library was not built."""
+    import ctypes
+    path = os.path.join(ROOT, "tools", "libpq_probe.so")
+    if not os.path.exists(path) or dtype != torch.bfloat16:
+        return None
+    lib = ctypes.CDLL(path)
+    lib.pq_probe_mfma.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.pq_probe_mfma.restype = ctypes.c_int
+    n_in, blocks, iters = 65536, 256, 4000
+    ops_in = torch.randn(n_in * 8, device=device).to(dtype)
+    out = torch.empty(blocks * 512, device=device, dtype=torch.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        rc = lib.pq_probe_mfma(ops_in.data_ptr(), n_in, out.data_ptr(), blocks, iters, stream)
+        assert rc == 0, f"pq_probe_mfma failed ({rc})"
+    flops = blocks * 8 * iters * 32 * 16384.0
+    launch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:      # clocks settle under sustained load
+        for _ in range(20):
+            launch()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 40
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return flops * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12
 
 
 def profiled_traffic(key):
@@ -520,6 +594,13 @@ def main():
     roof["traffic"] = profiled_traffic(f"{dom}@T{T}:{kname}") if world == 1 else None
     roof.update({"kernel": f"{kname}:{dom}", "launch_us": t_k * 1e6, "launches_timed": reps,
                  "algorithmic_bytes": k_bytes, "algorithmic_flops": k_flops})
+    if roof["bound"] == "mfma" and rank == 0:
+        ceil = mfma_ceiling(device, dtype)
+        if ceil:
+            # measured in this run on this device: a bare MFMA loop on operands drawn like the benchmark's
+            roof["measured_ceiling"] = {"value": ceil, "unit": "TFLOP/s", "frac_of_ceiling": roof["achieved"] / ceil,
+                                        "what": "bare v_mfma_f32_16x16x32_bf16 loop, normal operands in registers, "
+                                                "2 waves per SIMD, after 1.5 s of load"}
 
     decode = None
     if not args.no_decode and args.decode_tokens != T:

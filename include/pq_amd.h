@@ -66,6 +66,7 @@ typedef enum pq_status {
 #define PQ_CAP_ELEMENTWISE (1ull << 6) /* pq_silu_and_mul, pq_rms_norm, pq_fused_add_rms_norm */
 #define PQ_CAP_FUSED_SILU_MUL (1ull << 7) /* pq_gemm_packed_silu_mul runs fused for small batches */
 #define PQ_CAP_EMBEDDING (1ull << 8)      /* pq_embedding */
+#define PQ_CAP_FUSED_ADD_NORM (1ull << 9) /* pq_gemm_packed_add_norm / pq_gemm_packed_normed */
 
 /* Version of this ABI (PQ_ABI_VERSION) and capability bits.  No reference counterpart. */
 int pq_version(void);
@@ -232,6 +233,42 @@ int pq_gemm_packed_silu_mul(const void *x, int32_t T, int64_t x_row_stride, cons
                             int32_t G, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype, void *y,
                             int64_t y_row_stride, void *tmp /* nullable */, void *workspace, size_t workspace_bytes,
                             void *stream);
+
+/*
+ * A fused add + RMSNorm between two PQ linears, carried by the two GEMMs either side of it -- the pair a decoder
+ * layer runs as  x = o_proj(...); x, residual = post_attention_layernorm(x, residual); mlp(x)  and, across layers,
+ * down_proj -> input_layernorm -> qkv_proj (vllm/model_executor/models/llama.py:272-284 with RMSNorm.forward's fused
+ * add, vllm/model_executor/layers/layernorm.py:50-80).  Decode batches only (what the decode kernel takes: d = 8,
+ * one codebook of up to 256 entries, one-byte packed codes, at most 128 tokens); the _supported() queries say
+ * whether a problem runs, and a caller whose pair is not supported on both sides runs the three separate steps.
+ * Not for a row-parallel layer whose output is summed over ranks first (tensor parallelism > 1).
+ *
+ *   pq_gemm_packed_add_norm: r = pq_gemm_packed(x, ...) + residual in fp32; `residual` [T][N] is overwritten with r
+ *     (rounded once), xw [T][N] = r * norm_weight (rounded once), ssq [N / 16][Tp] (fp32, Tp = T rounded up to 16)
+ *     receives the sum of r^2 over each 16-row fragment, per token.
+ *   pq_gemm_packed_normed: y = pq_gemm_packed(xw, ...) with the accumulated sum multiplied by
+ *     rsqrt(sum over fragments of ssq / hidden + eps) of its token before scale and bias; hidden = in_features.
+ *
+ * Against the reference's three steps the roundings differ: the reference rounds the first GEMM's output, then the
+ * sum, then x / rms, then (x / rms) * w, each to the act dtype; here r is rounded once for the residual, r * w once,
+ * and 1 / rms multiplies the second GEMM's fp32 sum.  The results agree to the accuracy of the act dtype (tests state
+ * the tolerance); the new residual is the more accurate of the two.  No reference counterpart as one operator.
+ */
+int pq_gemm_packed_add_norm_supported(int32_t T, const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G,
+                                      int32_t M, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype);
+int pq_gemm_packed_normed_supported(int32_t T, const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G,
+                                    int32_t M, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype);
+int pq_gemm_packed_add_norm(const void *x, int32_t T, int64_t x_row_stride, const void *packed_codes,
+                            const void *codebooks, const void *scales, const void *bias /* nullable */,
+                            const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K,
+                            int32_t d, int32_t code_bytes, int32_t dtype, void *residual, int64_t residual_row_stride,
+                            const void *norm_weight, void *xw, int64_t xw_row_stride, float *ssq, void *workspace,
+                            size_t workspace_bytes, void *stream);
+int pq_gemm_packed_normed(const void *xw, int32_t T, int64_t xw_row_stride, const void *packed_codes,
+                          const void *codebooks, const void *scales, const void *bias /* nullable */,
+                          const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K,
+                          int32_t d, int32_t code_bytes, int32_t dtype, const float *ssq, float eps, void *y,
+                          int64_t y_row_stride, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Small-message all-reduce (SUM) between the tensor-parallel ranks of one node, one process per GPU, over device

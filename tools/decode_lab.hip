@@ -50,6 +50,7 @@ static void run(const Shape &sh, int T, int waves_force, int nf_force, bool stam
     p.x = (const unsigned char *)x; p.codebooks = (const unsigned char *)cb; p.scales = (const uint16_t *)sc; p.bias = nullptr;
     p.y = (uint16_t *)y; p.y_stride = N; p.x_stride_bytes = sh.Kin * 2; p.T = T; p.nchunks = nchunks; p.K = K; p.nf = g.nf;
     p.wk_log2 = g.wk_log2; p.img_bytes = K * 256; p.spt = K * 16 >= g.waves * 64 ? K * 16 / (g.waves * 64) : 1;
+    p.aux_off = (uint32_t)dc_lds_main_bytes(g.waves, p.img_bytes);
     p.ksplit = g.ksplit; p.cpb = g.cpb; p.n_total = N; p.ws_cnt = (unsigned *)a.workspace;
     p.ws_part = (float *)((unsigned char *)a.workspace + WS_COUNTER_BYTES);
     const int rows = (g.waves >> g.wk_log2) * g.nf * 16;

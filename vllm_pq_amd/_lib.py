@@ -20,7 +20,8 @@ EXPORTS = ("pq_version", "pq_caps", "pq_last_error", "pq_dequant", "pq_gemm_work
            "pq_rms_norm", "pq_fused_add_rms_norm", "pq_gemm_silu_mul_is_fused", "pq_gemm_packed_silu_mul", "pq_embedding",
            "pq_debug_reload_knobs", "pq_gemm_workspace_max_bytes", "pq_gemm_packed_noalloc", "pq_ar_last_error", "pq_ar_buffer_bytes",
            "pq_ar_max_message_bytes", "pq_ar_alloc", "pq_ar_free", "pq_ar_open", "pq_ar_close", "pq_ar_create",
-           "pq_ar_destroy", "pq_ar_all_reduce", "pq_ar_status")
+           "pq_ar_destroy", "pq_ar_all_reduce", "pq_ar_status", "pq_gemm_packed_add_norm_supported",
+           "pq_gemm_packed_normed_supported", "pq_gemm_packed_add_norm", "pq_gemm_packed_normed")
 
 _lock = threading.Lock()
 _lib = None
@@ -90,6 +91,15 @@ def load():
         L.pq_gemm_packed_silu_mul.argtypes = [vp, i32, i64, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp,
                                               vp, sz, vp]
         L.pq_gemm_packed_silu_mul.restype = ctypes.c_int
+        for fn in (L.pq_gemm_packed_add_norm_supported, L.pq_gemm_packed_normed_supported):
+            fn.argtypes = [i32, pi32, i32, i32, i32, i32, i32, i32, i32, i32]
+            fn.restype = ctypes.c_int
+        L.pq_gemm_packed_add_norm.argtypes = [vp, i32, i64, vp, vp, vp, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32,
+                                              vp, i64, vp, vp, i64, vp, vp, sz, vp]
+        L.pq_gemm_packed_add_norm.restype = ctypes.c_int
+        L.pq_gemm_packed_normed.argtypes = [vp, i32, i64, vp, vp, vp, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32,
+                                            vp, f32, vp, i64, vp, sz, vp]
+        L.pq_gemm_packed_normed.restype = ctypes.c_int
         L.pq_debug_reload_knobs.argtypes = []
         L.pq_debug_reload_knobs.restype = None
         pvp = ctypes.POINTER(vp)

@@ -135,7 +135,7 @@ int pq_version(void) { return PQ_ABI_VERSION; }
 
 uint64_t pq_caps(void) {
     return PQ_CAP_DEQUANT | PQ_CAP_GEMM | PQ_CAP_MFMA_SMALL_T | PQ_CAP_MFMA_TILED | PQ_CAP_BF16 | PQ_CAP_FP16 |
-           PQ_CAP_ELEMENTWISE | PQ_CAP_FUSED_SILU_MUL | PQ_CAP_EMBEDDING;
+           PQ_CAP_ELEMENTWISE | PQ_CAP_FUSED_SILU_MUL | PQ_CAP_EMBEDDING | PQ_CAP_FUSED_ADD_NORM;
 }
 
 const char *pq_last_error(void) { return g_err; }
@@ -453,6 +453,80 @@ int pq_gemm_packed_silu_mul(const void *x, int32_t T, int64_t x_row_stride, cons
                   code_bytes, dtype, tmp, 2 * (int64_t)I, workspace, workspace_bytes, stream);
     if (rc) return rc;
     return pq_silu_and_mul(tmp, 2 * (int64_t)I, T, I, dtype, y, y_row_stride, stream);
+}
+
+// ---- fused add + RMSNorm carried by the GEMMs either side of it (decode kernel) --------------------------------
+static int norm_common(const char *fn, pq::NormFuse &nf, const void *x, int32_t T, int64_t x_row_stride,
+                       const void *packed_codes, const void *codebooks, const void *scales, const void *bias,
+                       const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d,
+                       int32_t code_bytes, int32_t dtype, void *y, int64_t y_row_stride, void *workspace,
+                       size_t workspace_bytes, void *stream, bool query) {
+    pq::GemmArgs a;
+    void *al = reinterpret_cast<void *>(uintptr_t(256));   // queries: aligned dummy pointers
+    int rc = fill_gemm(a, fn, query ? al : x, T, query ? (int64_t)G * d : x_row_stride, query ? al : packed_codes,
+                       query ? al : codebooks, query ? al : scales, query ? nullptr : bias, part_sizes, num_parts, N, G, M,
+                       K, d, code_bytes, dtype, query ? al : y, query ? (int64_t)N : y_row_stride);
+    if (rc) return rc;
+    if (T == 0 || N == 0) return query ? 0 : PQ_OK;
+    if (!query && (!x || !packed_codes || !codebooks || !scales))
+        return fail(PQ_ERR_INVALID_ARGUMENT, "%s: NULL tensor pointer", fn);
+    a.packed = true;
+    a.workspace = query ? al : workspace;
+    a.workspace_bytes = query ? pq::WS_COUNTER_BYTES + pq::WS_PARTIAL_BYTES : workspace_bytes;
+    a.norm = &nf;
+    if (!pq::packable(a.parts, G, d, K, M, code_bytes) || !pq::gemm_decode_norm_supported(a)) {
+        if (query) return 0;
+        return fail(PQ_ERR_UNSUPPORTED, "%s: not a problem the decode kernel fuses (see %s_supported()), or a tensor is "
+                    "misaligned", fn, fn);
+    }
+    if (query) return 1;
+    hipError_t e = pq::launch_gemm_decode(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "%s: %s", fn, hipGetErrorString(e));
+    return PQ_OK;
+}
+
+int pq_gemm_packed_add_norm_supported(int32_t T, const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G,
+                                      int32_t M, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype) {
+    void *al = reinterpret_cast<void *>(uintptr_t(256));
+    pq::NormFuse nf{1, al, (int64_t)N, al, al, (int64_t)N, static_cast<float *>(al), 0, 0.f};
+    const int r = norm_common("pq_gemm_packed_add_norm", nf, nullptr, T, 0, nullptr, nullptr, nullptr, nullptr, part_sizes,
+                              num_parts, N, G, M, K, d, code_bytes, dtype, nullptr, 0, nullptr, 0, nullptr, true);
+    return r == 1 ? 1 : 0;
+}
+
+int pq_gemm_packed_normed_supported(int32_t T, const int32_t *part_sizes, int32_t num_parts, int32_t N, int32_t G,
+                                    int32_t M, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype) {
+    void *al = reinterpret_cast<void *>(uintptr_t(256));
+    pq::NormFuse nf{2, nullptr, 0, nullptr, nullptr, 0, static_cast<float *>(al), G * d, 1e-5f};
+    const int r = norm_common("pq_gemm_packed_normed", nf, nullptr, T, 0, nullptr, nullptr, nullptr, nullptr, part_sizes,
+                              num_parts, N, G, M, K, d, code_bytes, dtype, nullptr, 0, nullptr, 0, nullptr, true);
+    return r == 1 ? 1 : 0;
+}
+
+int pq_gemm_packed_add_norm(const void *x, int32_t T, int64_t x_row_stride, const void *packed_codes,
+                            const void *codebooks, const void *scales, const void *bias, const int32_t *part_sizes,
+                            int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes,
+                            int32_t dtype, void *residual, int64_t residual_row_stride, const void *norm_weight, void *xw,
+                            int64_t xw_row_stride, float *ssq, void *workspace, size_t workspace_bytes, void *stream) {
+    const char *fn = "pq_gemm_packed_add_norm";
+    if (T > 0 && N > 0 && (!residual || !norm_weight || !xw || !ssq))
+        return fail(PQ_ERR_INVALID_ARGUMENT, "%s: NULL tensor pointer", fn);
+    pq::NormFuse nf{1, residual, residual_row_stride, norm_weight, xw, xw_row_stride, ssq, 0, 0.f};
+    // y is not written: the GEMM's output lives on as the new residual
+    return norm_common(fn, nf, x, T, x_row_stride, packed_codes, codebooks, scales, bias, part_sizes, num_parts, N, G, M, K,
+                       d, code_bytes, dtype, residual, residual_row_stride, workspace, workspace_bytes, stream, false);
+}
+
+int pq_gemm_packed_normed(const void *xw, int32_t T, int64_t xw_row_stride, const void *packed_codes,
+                          const void *codebooks, const void *scales, const void *bias, const int32_t *part_sizes,
+                          int32_t num_parts, int32_t N, int32_t G, int32_t M, int32_t K, int32_t d, int32_t code_bytes,
+                          int32_t dtype, const float *ssq, float eps, void *y, int64_t y_row_stride, void *workspace,
+                          size_t workspace_bytes, void *stream) {
+    const char *fn = "pq_gemm_packed_normed";
+    if (T > 0 && N > 0 && (!ssq || !y)) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: NULL tensor pointer", fn);
+    pq::NormFuse nf{2, nullptr, 0, nullptr, nullptr, 0, const_cast<float *>(ssq), G * d, eps};
+    return norm_common(fn, nf, xw, T, xw_row_stride, packed_codes, codebooks, scales, bias, part_sizes, num_parts, N, G, M,
+                       K, d, code_bytes, dtype, y, y_row_stride, workspace, workspace_bytes, stream, false);
 }
 
 }  // extern "C"

@@ -100,9 +100,38 @@ DecodeGeom choose_decode_geom(const GemmArgs &a) {
     return g;
 }
 
+bool gemm_decode_norm_supported(const GemmArgs &a) {
+    if (!a.norm || !gemm_decode_supported(a)) return false;
+    const NormFuse &n = *a.norm;
+    const DecodeGeom g = choose_decode_geom(a);
+    if (g.nf == 0) return false;
+    if (n.role == 1) {
+        if (!n.residual || !n.norm_w || !n.xw || !n.ssq) return false;
+        if ((reinterpret_cast<uintptr_t>(n.residual) | reinterpret_cast<uintptr_t>(n.norm_w) | reinterpret_cast<uintptr_t>(n.xw)) & 7) return false;
+        if (n.res_stride % 4 || n.xw_stride % 4 || n.res_stride < a.N || n.xw_stride < a.N) return false;
+        return (uint64_t)a.T * (uint64_t)n.res_stride * 2 < (1ull << 31);
+    }
+    if (n.role == 2) {
+        // every thread adds at most eight fragments' sums for its token
+        return n.ssq && n.hidden == a.G * a.d && n.hidden % 16 == 0 && n.hidden / 16 <= 8 * (g.waves * 4);
+    }
+    return false;
+}
+
 template <typename AT>
 static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipStream_t stream) {
     DecodeParams p;
+    p.residual = nullptr; p.res_stride = 0; p.norm_w = nullptr; p.xw = nullptr; p.xw_stride = 0; p.ssq = nullptr;
+    p.t_pad = (a.T + 15) & ~15; p.ssq_frags = 0; p.eps = 0.f; p.inv_hidden = 0.f;
+    const int role = a.norm ? a.norm->role : 0;
+    if (role == 1) {
+        p.residual = static_cast<uint16_t *>(a.norm->residual); p.res_stride = a.norm->res_stride;
+        p.norm_w = static_cast<const uint16_t *>(a.norm->norm_w);
+        p.xw = static_cast<uint16_t *>(a.norm->xw); p.xw_stride = a.norm->xw_stride;
+        p.ssq = a.norm->ssq;
+    } else if (role == 2) {
+        p.ssq = a.norm->ssq; p.ssq_frags = a.norm->hidden / 16; p.eps = a.norm->eps; p.inv_hidden = 1.0f / (float)a.norm->hidden;
+    }
     p.x = static_cast<const unsigned char *>(a.x);
     p.codes = static_cast<const unsigned char *>(a.codes);
     p.codebooks = static_cast<const unsigned char *>(a.codebooks);
@@ -118,6 +147,7 @@ static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipSt
     p.wk_log2 = g.wk_log2;
     p.img_bytes = (uint32_t)a.K * 256u;
     p.spt = a.K * 16 >= g.waves * 64 ? a.K * 16 / (g.waves * 64) : 1;
+    p.aux_off = (uint32_t)dc_lds_main_bytes(g.waves, p.img_bytes);
     p.ksplit = g.ksplit;
     p.cpb = g.cpb;
     p.n_total = a.N;
@@ -140,11 +170,14 @@ static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipSt
         hipLaunchKernelGGL(kern, grid, dim3(g.waves * 64), lds, stream, p);
         return hipGetLastError();
     };
+    if (role == 1) return launch(gemm_decode_kernel<AT, false, 0, 1>);
+    if (role == 2) return launch(gemm_decode_kernel<AT, false, 0, 2>);
     return launch(gemm_decode_kernel<AT>);
 }
 
 hipError_t launch_gemm_decode(const GemmArgs &a, hipStream_t stream) {
     if (a.N == 0 || a.T == 0) return hipSuccess;
+    if (a.norm && !gemm_decode_norm_supported(a)) return hipErrorInvalidValue;
     const DecodeGeom g = choose_decode_geom(a);
     if (g.nf == 0) return hipErrorInvalidValue;
     return a.dtype == PQ_DTYPE_BF16 ? launch_decode_at<bf16_t>(a, g, stream) : launch_decode_at<fp16_t>(a, g, stream);

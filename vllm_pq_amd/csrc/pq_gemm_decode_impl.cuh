@@ -37,10 +37,11 @@ constexpr int DC_UMAX = 8;                       // units of a wave (chunks x fr
 constexpr int DC_STAGE_BYTES = DC_MAX_WAVES * DC_UMAX * 1024;
 constexpr int DC_XROW_BYTES = 1040;               // a token's KiB of a chunk in LDS, padded by one 16-byte slot
 // LDS of a block of `waves` waves with a codebook image of img_bytes: image + staging, or the activation regions
-constexpr size_t dc_lds_bytes(int waves, size_t img_bytes) {
+constexpr size_t dc_lds_main_bytes(int waves, size_t img_bytes) {
     const size_t a = img_bytes + (size_t)waves * DC_UMAX * 1024, b = (size_t)waves * 16 * DC_XROW_BYTES;
     return a > b ? a : b;
 }
+constexpr size_t dc_lds_bytes(int waves, size_t img_bytes) { return dc_lds_main_bytes(waves, img_bytes) + 512; }
 
 struct DecodeParams {
     const unsigned char *x;        // [T][x_stride] act dtype
@@ -60,11 +61,24 @@ struct DecodeParams {
     int spt;                       // 16-byte image slots per thread: max(1, K * 16 / threads per block)
     // K split over blocks (longer K than 8 chunks): block (x, y) takes chunks y * cpb .. + cpb - 1 of tile x; the fp32
     // partial sums [ksplit][T][n_total] meet in the workspace (the streaming kernel's protocol and layout)
+    uint32_t aux_off;              // LDS offset of 512 bytes behind everything else (MODE 2: per-wave sums of squares)
     int ksplit;                    // blocks per tile = gridDim.y (1: no split, no workspace)
     int cpb;                       // chunks per block (at most 1 << wk_log2)
     int n_total;                   // output rows of the whole layer
     float *ws_part;
     unsigned *ws_cnt;              // one arrival counter per tile, zero between launches
+    // MODE 1 (the GEMM in front of a fused add + RMSNorm): r = y + residual is written back as the new residual,
+    // r * norm_w goes to xw, and the sum of squares of r per 16-row fragment and token to ssq[fragment][t_pad]
+    uint16_t *residual;            // [T][res_stride], read and written
+    int64_t res_stride;
+    const uint16_t *norm_w;        // [n_total]
+    uint16_t *xw;                  // [T][xw_stride]
+    int64_t xw_stride;
+    float *ssq;                    // MODE 1: written; MODE 2: read, [ssq_frags][t_pad]
+    int t_pad;                     // tokens rounded up to 16
+    // MODE 2 (the GEMM behind it): x holds r * norm_w; y is multiplied by rsqrt(sum of r^2 / hidden + eps) per token
+    int ssq_frags;                 // fragments summed per token (hidden / 16)
+    float eps, inv_hidden;
     TileMap tmap;                  // tiles of (blockDim/64 >> wk_log2) * nf * 16 rows
 };
 
@@ -129,7 +143,8 @@ __device__ __forceinline__ void dc_wait_vm(int n) {
 
 // STAMPS (diagnostic builds only): thread 0 writes wall-clock stamps of the phases to `bias` (8 x u64 per block)
 // ABL (diagnostic builds only; 0 in the library): bit 0 leaves the MFMAs of the units out, bit 1 the gathers
-template <typename AT, bool STAMPS = false, int ABL = 0>
+// MODE: 0 the plain linear; 1 and 2 the two halves of a fused add + RMSNorm between two linears (DecodeParams)
+template <typename AT, bool STAMPS = false, int ABL = 0, int MODE = 0>
 __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const DecodeParams p) {
     typedef typename Act<AT>::vec8 vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -200,6 +215,20 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
         ++issued;
     }
 
+    // MODE 2: this thread's share of the per-fragment sums of squares of its token (tid & 15): fragments tid >> 4,
+    // + threads / 16, ... (at most eight: checked on the host), requested here and added once the activations have
+    // landed
+    float ssq_v[8];
+    if constexpr (MODE == 2) {
+        const int fstep = (int)(blockDim.x >> 4);
+        const float *sp = p.ssq + tok0 + (tid & 15);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = (tid >> 4) + j * fstep;
+            ssq_v[j] = sp[(size_t)(f < p.ssq_frags ? f : p.ssq_frags - 1) * p.t_pad];
+        }
+    }
+
     // ---- activations: token t's KiB of the wave's chunk -> row t of the wave's region.  With at most 8 tokens only
     // 8 rows are brought in (columns 8..15 of the MFMAs then read whatever the LDS holds: those outputs are never
     // stored, and a column's values do not reach another column).  Tokens past T repeat the last one.
@@ -254,6 +283,18 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
 #undef DC_XD
     }
     DC_STAMP(4)   // operands in registers
+    if constexpr (MODE == 2) {
+        float ssq_part = 0.f;
+        const int fstep = (int)(blockDim.x >> 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            asm volatile("" : "+v"(ssq_v[j]));      // used from here on: behind the wait for the activations
+            ssq_part += ((tid >> 4) + j * fstep < p.ssq_frags) ? ssq_v[j] : 0.f;
+        }
+        ssq_part += __shfl_xor(ssq_part, 16);
+        ssq_part += __shfl_xor(ssq_part, 32);
+        if (lane < 16) reinterpret_cast<float *>(smem + p.aux_off)[wave * 16 + lane] = ssq_part;
+    }
     __syncthreads();   // every wave has its activations out of the LDS: image and staging may be written
     DC_STAMP(5)   // barrier
 
@@ -270,6 +311,14 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     ++issued;
     u32x2 biv = dc_gload8((uint32_t)out_row * 2u, bias ? bias : p.scales);   // without a bias: loaded, never used
     ++issued;
+    u32x2 rsv{0u, 0u}, nwv{0u, 0u};
+    if constexpr (MODE == 1) {   // the lane's four residual values (its token, its rows) and norm weights
+        const int tl = (lane & 15) < T ? (lane & 15) : T - 1;
+        rsv = dc_gload8((uint32_t)((int64_t)(tok0 + tl) * p.res_stride + out_row) * 2u, p.residual);
+        ++issued;
+        nwv = dc_gload8((uint32_t)out_row * 2u, p.norm_w);
+        ++issued;
+    }
     DC_STAMP(6)   // everything requested
     if (img_active) {
         if (spt == 8) {
@@ -366,24 +415,58 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dc_landed(scv);
     dc_landed(biv);
+    if constexpr (MODE == 1) { dc_landed(rsv); dc_landed(nwv); }
     DC_STAMP(9)   // this wave's units done
     __syncthreads();
     DC_STAMP(10)   // all waves' units done
 
     // ---- epilogue: the partial sums of the output fragment over the waves along K, in a fixed order -------------------
     const int t_out = lane & 15;
+    float rinv = 1.f;
+    if constexpr (MODE == 2) {   // 1 / rms of the token: the waves' partial sums in wave order
+        const float *wp = reinterpret_cast<const float *>(smem + p.aux_off) + t_out;
+        float ss = wp[0];
+        const int nw = (int)(blockDim.x >> 6);
+#pragma nounroll
+        for (int w = 1; w < nw; ++w) ss += wp[w * 16];
+        rinv = rsqrtf(ss * p.inv_hidden + p.eps);
+    }
+    float ss_lane = 0.f;         // MODE 1: sum of squares of this lane's four values of r
     auto finish = [&](const f32x4 &sum) {   // scale, bias, one rounding, 8-byte store (y and its row stride are 8-byte aligned: host)
-        const uint32_t sw[2] = {scv.x, scv.y}, bw[2] = {biv.x, biv.y};
-        uint16_t h[4];
+        const uint32_t sw[2] = {scv.x, scv.y}, bw[2] = {biv.x, biv.y}, rw[2] = {rsv.x, rsv.y}, nw2[2] = {nwv.x, nwv.y};
+        uint16_t h[4], hx[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint16_t s16 = (uint16_t)(sw[e >> 1] >> ((e & 1) * 16)), b16 = (uint16_t)(bw[e >> 1] >> ((e & 1) * 16));
-            h[e] = Act<AT>::from_f32(sum[e] * Act<AT>::to_f32(s16) + (bias ? Act<AT>::to_f32(b16) : 0.0f));
+            float v = (MODE == 2 ? sum[e] * rinv : sum[e]) * Act<AT>::to_f32(s16) + (bias ? Act<AT>::to_f32(b16) : 0.0f);
+            if constexpr (MODE == 1) {
+                v += Act<AT>::to_f32((uint16_t)(rw[e >> 1] >> ((e & 1) * 16)));
+                ss_lane += v * v;
+                hx[e] = Act<AT>::from_f32(v * Act<AT>::to_f32((uint16_t)(nw2[e >> 1] >> ((e & 1) * 16))));
+            }
+            h[e] = Act<AT>::from_f32(v);
         }
         u32x2 o2;
         o2.x = h[0] | ((uint32_t)h[1] << 16);
         o2.y = h[2] | ((uint32_t)h[3] << 16);
-        *reinterpret_cast<u32x2 *>(p.y + (size_t)(tok0 + t_out) * p.y_stride + out_row) = o2;
+        if constexpr (MODE == 1) {
+            *reinterpret_cast<u32x2 *>(p.residual + (size_t)(tok0 + t_out) * p.res_stride + out_row) = o2;
+            u32x2 o3;
+            o3.x = hx[0] | ((uint32_t)hx[1] << 16);
+            o3.y = hx[2] | ((uint32_t)hx[3] << 16);
+            *reinterpret_cast<u32x2 *>(p.xw + (size_t)(tok0 + t_out) * p.xw_stride + out_row) = o3;
+        } else {
+            *reinterpret_cast<u32x2 *>(p.y + (size_t)(tok0 + t_out) * p.y_stride + out_row) = o2;
+        }
+    };
+    // MODE 1, by every wave that finished a fragment (wave-uniform condition): the fragment's sum of squares per token
+    auto put_ssq = [&]() {
+        if constexpr (MODE == 1) {
+            float ss = ss_lane;
+            ss += __shfl_xor(ss, 16);
+            ss += __shfl_xor(ss, 32);
+            if (lane < T) p.ssq[(size_t)(out_row >> 4) * p.t_pad + tok0 + lane] = ss;
+        }
     };
     if (out_wave) {
         const unsigned char *slot = smem + p.img_bytes + ((size_t)((wr << p.wk_log2) * DC_UMAX + wk) * 64 + lane) * 16;
@@ -397,6 +480,7 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
             if (p.ksplit == 1) finish(sum);
             else coherent_store16(p.ws_part + ((size_t)blockIdx.y * p.T + tok0 + t_out) * (size_t)p.n_total + out_row, sum);
         }
+        if (p.ksplit == 1) put_ssq();
     }
     // K split over blocks: every block counts itself in on its tile's counter; the last one to arrive adds the partial
     // sums up in split order (the result does not depend on which block that is), finishes the tile and leaves the
@@ -415,7 +499,8 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
             if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (s_last && out_wave && t_out < T) {
+        if (s_last && out_wave) {
+          if (t_out < T) {
             f32x4 part[8];   // all requested before any is waited for; splits past the last re-read the last one
 #pragma unroll
             for (int z = 0; z < 8; ++z) {
@@ -431,6 +516,8 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
                 if (z < p.ksplit) { sum.x += part[z].x; sum.y += part[z].y; sum.z += part[z].z; sum.w += part[z].w; }
             }
             finish(sum);
+          }
+          put_ssq();
         }
     }
     if constexpr (STAMPS) {

@@ -17,6 +17,22 @@ struct DequantArgs {
     void *out;
 };
 
+// A fused add + RMSNorm between two linears, split over the two GEMMs either side of it (decode kernel only).
+//   role 1, the GEMM in front: r = y + residual replaces the residual, xw = r * norm_w, ssq[fragment][t_pad] = the sum
+//           of r^2 over the fragment's 16 rows, per token (t_pad = T rounded up to 16);
+//   role 2, the GEMM behind: x is xw, and y is multiplied by rsqrt(sum over fragments of ssq / hidden + eps).
+struct NormFuse {
+    int role;
+    void *residual;
+    int64_t res_stride;
+    const void *norm_w;
+    void *xw;
+    int64_t xw_stride;
+    float *ssq;
+    int hidden;
+    float eps;
+};
+
 struct GemmArgs {
     const void *x;
     int T;
@@ -32,6 +48,7 @@ struct GemmArgs {
     void *workspace;
     size_t workspace_bytes;
     bool packed;  // codes are in the kernel-native PACKED order (pq_gemm_stream.hip)
+    const NormFuse *norm = nullptr;   // the launch is one half of a fused add + RMSNorm (decode kernel only)
 };
 
 hipError_t launch_dequant(const DequantArgs &a, hipStream_t stream);
@@ -77,6 +94,8 @@ bool gemm_decode_preferred(const GemmArgs &a);
 double decode_model_us(const GemmArgs &a);   // modelled launch duration (0: not taken), for batches beyond 16 tokens
 DecodeGeom choose_decode_geom(const GemmArgs &a);
 hipError_t launch_gemm_decode(const GemmArgs &a, hipStream_t stream);
+// Whether launch_gemm_decode takes this problem with a.norm set (role 1 or 2).
+bool gemm_decode_norm_supported(const GemmArgs &a);
 
 // Load-time re-layout of the codes for the MFMA kernels.
 bool stream_format_supported(int d, int K, int M, int code_bytes);

@@ -380,6 +380,93 @@ def pq_gemm_packed_silu_mul(input: torch.Tensor, packed_codes: torch.Tensor, cod
     return _pq_gemm_packed_silu_mul_impl(input, packed_codes, codes, codebooks, scales, bias)
 
 
+# ---- a fused add + RMSNorm carried by the PQ linears either side of it (decode batches) ------------
+def _norm_pair_args(codes, codebooks, partition_sizes):
+    N, G, M, K, d, parts = _format(codes, codebooks, partition_sizes)
+    return N, G, M, K, d, parts, _lib.parts_array(parts), _CODE_BYTES[codes.dtype]
+
+
+def gemm_add_norm_supported(T: int, codes: torch.Tensor, codebooks: torch.Tensor, partition_sizes) -> bool:
+    """Whether pq_gemm_packed_add_norm runs a batch of T tokens on this layer (the GEMM in front of the norm)."""
+    N, G, M, K, d, parts, pa, cb = _norm_pair_args(codes, codebooks, partition_sizes)
+    return bool(_lib.load().pq_gemm_packed_add_norm_supported(T, pa, len(parts), N, G, M, K, d, cb, _DTYPE[codebooks.dtype]))
+
+
+def gemm_normed_supported(T: int, codes: torch.Tensor, codebooks: torch.Tensor, partition_sizes) -> bool:
+    """Whether pq_gemm_packed_normed runs a batch of T tokens on this layer (the GEMM behind the norm)."""
+    N, G, M, K, d, parts, pa, cb = _norm_pair_args(codes, codebooks, partition_sizes)
+    return bool(_lib.load().pq_gemm_packed_normed_supported(T, pa, len(parts), N, G, M, K, d, cb, _DTYPE[codebooks.dtype]))
+
+
+def _rows16(t: torch.Tensor, cols: int, what: str) -> torch.Tensor:
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.shape[-1] != cols or t2.stride(-1) != 1 or t2.data_ptr() % 16 or t2.stride(0) % 8:
+        raise ValueError(f"{what}: [tokens, {cols}] with unit column stride, 16-byte aligned rows expected")
+    return t2
+
+
+def pq_gemm_packed_add_norm(input: torch.Tensor, packed_codes: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor,
+                            scales: torch.Tensor, codebook_partition_sizes: List[int], bias: Optional[torch.Tensor],
+                            residual: torch.Tensor, norm_weight: torch.Tensor):
+    """The linear in front of a fused add + RMSNorm: r = pq_gemm_packed(input, ...) + residual replaces `residual`
+    in place; returns (xw, ssq): r * norm_weight in the act dtype, and the per-fragment sums of r^2 [N / 16, Tp] that
+    pq_gemm_packed_normed turns into 1 / rms.  Raises NotImplementedError-like ValueError when the library does not
+    fuse the problem: ask gemm_add_norm_supported() first."""
+    L = _lib.load()
+    dev = _check_device(input, packed_codes, codes, codebooks, scales, bias, residual, norm_weight)
+    N, G, M, K, d, parts, pa, cb = _norm_pair_args(codes, codebooks, codebook_partition_sizes)
+    if input.dtype != codebooks.dtype or input.shape[-1] != G * d:
+        raise ValueError(f"input {tuple(input.shape)} {input.dtype} does not match the weight ({G * d} features, {codebooks.dtype})")
+    x2 = input.reshape(-1, input.shape[-1])
+    if x2.stride(-1) != 1 or x2.data_ptr() % 16 or x2.stride(0) % 8:
+        x2 = x2.contiguous()
+    T = x2.shape[0]
+    res2 = _rows16(residual, N, "residual")
+    if res2.shape[0] != T or residual.dtype != input.dtype or norm_weight.numel() != N or norm_weight.dtype != input.dtype:
+        raise ValueError("residual [tokens, out_features] and norm_weight [out_features] of the activation dtype expected")
+    xw = torch.empty((T, N), dtype=input.dtype, device=dev)
+    ssq = torch.empty((N // 16, (T + 15) // 16 * 16), dtype=torch.float32, device=dev)
+    if T and N:
+        with torch.cuda.device(dev):
+            ws = _workspace(dev)
+            rc = L.pq_gemm_packed_add_norm(
+                x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, packed_codes.data_ptr(), codebooks.contiguous().data_ptr(),
+                scales.contiguous().data_ptr(), bias.contiguous().data_ptr() if bias is not None else None, pa, len(parts),
+                N, G, M, K, d, cb, _DTYPE[input.dtype], res2.data_ptr(), res2.stride(0) if T > 1 else N,
+                norm_weight.contiguous().data_ptr(), xw.data_ptr(), N, ssq.data_ptr(),
+                ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream_ptr(dev))
+        if rc:
+            _raise(rc)
+    return xw.reshape(input.shape[:-1] + (N,)), ssq
+
+
+def pq_gemm_packed_normed(xw: torch.Tensor, ssq: torch.Tensor, eps: float, packed_codes: torch.Tensor, codes: torch.Tensor,
+                          codebooks: torch.Tensor, scales: torch.Tensor, codebook_partition_sizes: List[int],
+                          bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """The linear behind a fused add + RMSNorm: pq_gemm_packed(xw, ...) with every token's sum multiplied by
+    rsqrt(mean of r^2 + eps) before scale and bias; (xw, ssq) come from pq_gemm_packed_add_norm."""
+    L = _lib.load()
+    dev = _check_device(xw, ssq, packed_codes, codes, codebooks, scales, bias)
+    N, G, M, K, d, parts, pa, cb = _norm_pair_args(codes, codebooks, codebook_partition_sizes)
+    x2 = _rows16(xw, G * d, "xw")
+    T = x2.shape[0]
+    if xw.dtype != codebooks.dtype or ssq.dtype != torch.float32 or tuple(ssq.shape) != (G * d // 16, (T + 15) // 16 * 16) \
+            or not ssq.is_contiguous():
+        raise ValueError("xw of the weight's dtype and ssq [in_features / 16, tokens rounded up to 16] fp32 expected")
+    out = torch.empty((T, N), dtype=xw.dtype, device=dev)
+    if T and N:
+        with torch.cuda.device(dev):
+            ws = _workspace(dev)
+            rc = L.pq_gemm_packed_normed(
+                x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, packed_codes.data_ptr(), codebooks.contiguous().data_ptr(),
+                scales.contiguous().data_ptr(), bias.contiguous().data_ptr() if bias is not None else None, pa, len(parts),
+                N, G, M, K, d, cb, _DTYPE[xw.dtype], ssq.data_ptr(), float(eps), out.data_ptr(), N,
+                ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream_ptr(dev))
+        if rc:
+            _raise(rc)
+    return out.reshape(xw.shape[:-1] + (N,))
+
+
 # ---- the element-wise neighbours of the linears -------------------------------------------------
 # Same names, argument order and in-place conventions as the reference's wrappers
 # (vllm/_custom_ops.py:151-158 rms_norm / fused_add_rms_norm; torch.ops._C.silu_and_mul as called from

@@ -221,6 +221,38 @@ class PQLinearMethod(LinearMethodBase):
         return ops.pq_gemm_packed_silu_mul(x, packed, layer.codes, layer.codebooks, layer.scales, bias)
 
 
+    # ---- a fused add + RMSNorm between two PQ linears (decode batches, no tensor parallelism on the first) ----
+    def norm_pair_supported(self, first: torch.nn.Module, second: torch.nn.Module, tokens: int) -> bool:
+        """Whether `first` (the linear whose output a fused add + RMSNorm takes: o_proj, down_proj) and `second` (the
+        linear behind the norm: gate_up_proj, qkv_proj) run a batch of `tokens` as apply_add_norm / apply_normed."""
+        for layer in (first, second):
+            if getattr(layer, "pq_packed_codes", None) is None:
+                return False
+        if getattr(first, "tp_size", 1) > 1 and getattr(first, "reduce_results", False):
+            return False            # the sum over ranks comes between the GEMM and the add
+        pf = getattr(first.codebooks, "output_partition_sizes", [])
+        ps = getattr(second.codebooks, "output_partition_sizes", [])
+        return (first.codes.shape[0] == second.codes.shape[1] * second.codebooks.shape[3]
+                and ops.gemm_add_norm_supported(tokens, first.codes, first.codebooks, pf)
+                and ops.gemm_normed_supported(tokens, second.codes, second.codebooks, ps))
+
+    def apply_add_norm(self, layer: torch.nn.Module, x: torch.Tensor, residual: torch.Tensor,
+                       norm_weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+        """apply() of the linear in front of `RMSNorm.forward(x, residual)` (vllm/model_executor/layers/layernorm.py:
+        50-80 with the fused add): `residual` becomes apply(x) + residual in place; returns (xw, ssq) for apply_normed
+        of the linear behind the norm."""
+        parts = getattr(layer.codebooks, "output_partition_sizes", [])
+        return ops.pq_gemm_packed_add_norm(x, layer.pq_packed_codes, layer.codes, layer.codebooks, layer.scales, parts,
+                                           bias, residual, norm_weight)
+
+    def apply_normed(self, layer: torch.nn.Module, xw: torch.Tensor, ssq: torch.Tensor, eps: float,
+                     bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """apply(norm(...)) of the linear behind the norm, from what apply_add_norm returned."""
+        parts = getattr(layer.codebooks, "output_partition_sizes", [])
+        return ops.pq_gemm_packed_normed(xw, ssq, eps, layer.pq_packed_codes, layer.codes, layer.codebooks, layer.scales,
+                                         parts, bias)
+
+
 class PQEmbeddingMethod(PQLinearMethod):
     """PQ-compressed vocabulary table: [rows of this rank, embedding_dim] as one output partition.  apply() gives
     the LM head's logits (the linear method's fused GEMM), embedding() the rows of the reconstructed table picked
