@@ -123,7 +123,19 @@ def enable_launch_log(stack, dtype):
         record(input, codes, codebooks, [codes.shape[0] // 2] * 2, True, fused="+silu_mul")
         return fused(input, packed_codes, codes, codebooks, scales, bias)
 
+    add_norm, normed = ops.pq_gemm_packed_add_norm, ops.pq_gemm_packed_normed
+
+    def gemm_packed_add_norm(input, packed_codes, codes, codebooks, scales, codebook_partition_sizes, bias, residual,
+                             norm_weight):
+        record(input, codes, codebooks, codebook_partition_sizes, True, fused="+add_norm")
+        return add_norm(input, packed_codes, codes, codebooks, scales, codebook_partition_sizes, bias, residual, norm_weight)
+
+    def gemm_packed_normed(xw, ssq, eps, packed_codes, codes, codebooks, scales, codebook_partition_sizes, bias):
+        record(xw, codes, codebooks, codebook_partition_sizes, True, fused="+normed")
+        return normed(xw, ssq, eps, packed_codes, codes, codebooks, scales, codebook_partition_sizes, bias)
+
     ops.pq_gemm, ops.pq_gemm_packed, ops.pq_gemm_packed_silu_mul = gemm, gemm_packed, gemm_packed_silu_mul
+    ops.pq_gemm_packed_add_norm, ops.pq_gemm_packed_normed = gemm_packed_add_norm, gemm_packed_normed
 
 
 class Graph:

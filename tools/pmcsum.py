@@ -12,7 +12,12 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in files:
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        name = name[name.find("pq::"):][:60] if "pq::" in name else name[:40]
+        if "pq::" in name:
+            name = name[name.find("pq::"):][:60]
+        elif "_ZN2pq" in name:                      # a kernel whose name came out mangled
+            name = "pq::" + name[name.find("_ZN2pq") + 6:][:56]
+        else:
+            name = name[:40]
         key = (name, r.get("Grid_Size", r.get("Grid_Size_X", "")))
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for key, ctrs in agg.items():

@@ -17,6 +17,7 @@ echo "[6/6] summaries"
 python3 "$R/tools/proftrace.py" "$O/kt" --launch-log "$O/launches.json" > "$O/kernel_trace_summary.txt"
 rm -f "$O/launches.json"
 for p in fetch write sq; do echo "== $p"; python3 "$R/tools/pmcsum.py" "$O/pmc_$p"; done > "$O/pmc_summary.txt"
+python3 "$R/tools/traffic.py" "$O/pmc_fetch" "$O/pmc_write" "$TAG" > "$O/traffic.json"
 find "$O/kt" -name "*kernel_stats.csv" -exec cp {} "$O/kernel_stats.csv" \;
 # raw traces are large; keep only the summaries in what travels back
 rm -rf "$O/kt" "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_sq"

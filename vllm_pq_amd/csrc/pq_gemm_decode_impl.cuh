@@ -35,7 +35,10 @@ constexpr int DC_MAX_WAVES = 8;
 constexpr int DC_MAX_TOKENS = 128;                // batches beyond 16 tokens run as groups of 16 over gridDim.z
 constexpr int DC_UMAX = 8;                       // units of a wave (chunks x fragments): 1 KiB of staging each
 constexpr int DC_STAGE_BYTES = DC_MAX_WAVES * DC_UMAX * 1024;
-constexpr int DC_XROW_BYTES = 1040;               // a token's KiB of a chunk in LDS, padded by one 16-byte slot
+// A token's KiB of a chunk in LDS, padded by two 16-byte slots: ds_read_b128 serves lanes {0-3, 12-15, 20-27} (and
+// the three like groups) in one cycle each, i.e. 8 tokens c at k-octet q and the other 8 at q + 1; with rows
+// 2 slots (mod 16) apart those 16 lanes read slots 2 c + q, all different mod 16: no bank conflict.
+constexpr int DC_XROW_BYTES = 1056;
 // LDS of a block of `waves` waves with a codebook image of img_bytes: image + staging, or the activation regions
 constexpr size_t dc_lds_main_bytes(int waves, size_t img_bytes) {
     const size_t a = img_bytes + (size_t)waves * DC_UMAX * 1024, b = (size_t)waves * 16 * DC_XROW_BYTES;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     // different rows, and the memory pipeline takes such a wave-load at a quarter of the rate of one whose quads each
     // read 64 contiguous bytes (measured, tools/ingest_lab.hip: 128 KiB per block in 4.0 us against 1.6).  So a wave
     // brings its chunk of every token in as ONE contiguous KiB per token, by LDS-DMA, into a padded LDS region of its
-    // own (16 rows of 1040 bytes: the 16 bytes of padding put the 16 tokens of a k-step on different banks), and reads
+    // own (16 rows of 1056 bytes: the padding puts the lanes one LDS cycle serves on different banks), and reads
     // the 16 operand registers from there (lane (q, c): row c, byte 64 s + 16 q).  The region lies where the codebook
     // image and the code staging area are built AFTERWARDS: the activations are in registers by then.
     const int WK = 1 << p.wk_log2;

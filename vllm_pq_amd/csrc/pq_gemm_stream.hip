@@ -176,8 +176,10 @@ StreamCfg choose_stream_cfg(const GemmArgs &a, double *model_us) {
     static const StreamCfg wide[] = {{4, 4, 1}, {2, 4, 1}, {4, 2, 1}, {7, 2, 1}};
     StreamCfg best = wide[2];
     double best_us = -1.0;
+    const bool quad_gather = a.d == 2 && a.code_bytes == 2;   // four gathers per operand from an unreplicated image
     for (const StreamCfg &c : wide) {
         if (c.nf * c.tf > 8 && !light) continue;
+        if (quad_gather && a.T > 32 && !(c.nf == 4 && c.tf == 2)) continue;   // measured: 64 x 32 tiles, by 20 - 45 %
         if (c.tf == 4 && a.T <= 32) continue;   // half the token tile would be padding
         for (int want = 1; want <= smax; want *= 2) {
             if (forced && want != 1) continue;
