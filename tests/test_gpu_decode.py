@@ -163,3 +163,25 @@ def test_decode_kernel_model_shapes_full_size(ops, name, parts, Kin, T):
     assert not bad.any(), f"{name} T={T}: {int(bad.sum())} of {bad.numel()} outside tolerance"
     y2 = ops.pq_gemm_packed(x * 2, packed, codes, cb, scales, parts, None)
     assert torch.equal(y2, y * 2)
+
+
+def test_release_reference_codes_keeps_apply_working(ops):
+    """With release_reference_codes the reference-layout tensor keeps shape and dtype but not its storage; apply()
+    (packed path) gives the same bits as before."""
+    from vllm_pq_amd import PQConfig
+    from vllm_pq_amd.host.linear import MergedColumnParallelLinear
+    outs = []
+    for release in (False, True):
+        torch.manual_seed(11)
+        layer = MergedColumnParallelLinear(1024, [256, 256], bias=False, params_dtype=torch.bfloat16,
+                                           quant_config=PQConfig(8, 8, 1, 1, release_reference_codes=release))
+        layer.codes.data = torch.randint(-128, 128, layer.codes.shape, dtype=torch.int8)
+        layer.codebooks.data = torch.randn(layer.codebooks.shape).to(torch.bfloat16)
+        layer.scales.data = (torch.rand(layer.scales.shape) + 0.5).to(torch.bfloat16)
+        layer.to(DEV)
+        layer.quant_method.process_weights_after_loading(layer)
+        assert tuple(layer.codes.shape) == (512, 128, 1) and layer.codes.dtype == torch.int8
+        assert layer.codes.untyped_storage().nbytes() == (1 if release else 512 * 128)
+        x = torch.randn(40, 1024, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).to(DEV)
+        outs.append((layer(x)[0], layer(x[:7])[0]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

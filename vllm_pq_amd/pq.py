@@ -52,8 +52,13 @@ class PQConfig(QuantizationConfig):
     out_group_size (must be 1)."""
 
     def __init__(self, in_group_size: int = 8, nbits_per_codebook: int = 8, num_codebooks: int = 1,
-                 out_group_size: int = 1, lm_head: bool = False, embeddings: bool = False) -> None:
+                 out_group_size: int = 1, lm_head: bool = False, embeddings: bool = False,
+                 release_reference_codes: bool = False) -> None:
         super().__init__()
+        # After the load-time re-layout the kernels read only the packed copy of a linear layer's codes; with this
+        # key (same name in the HF quantization_config) the reference-layout tensor gives its storage back (shape and
+        # dtype stay): half the code bytes of a model, at the price that pq_dequant on such a layer no longer works.
+        self.release_reference_codes = bool(release_reference_codes)
         # The reference's codebook method quantises linear layers only (aqlm.py:213-217), and so does this one by
         # default.  `lm_head` / `embeddings` (keys of the same names in the HF quantization_config) say that the
         # checkpoint also holds codes/codebooks/scales for the output head / the input embedding table.
@@ -104,7 +109,8 @@ class PQConfig(QuantizationConfig):
         m = cls.get_from_keys_or(config, ["num_codebooks"], 1)
         og = cls.get_from_keys_or(config, ["out_group_size"], 1)
         return cls(d, nbits, m, og, lm_head=cls.get_from_keys_or(config, ["lm_head"], False),
-                   embeddings=cls.get_from_keys_or(config, ["embeddings"], False))
+                   embeddings=cls.get_from_keys_or(config, ["embeddings"], False),
+                   release_reference_codes=cls.get_from_keys_or(config, ["release_reference_codes"], False))
 
     def get_quant_method(self, layer: torch.nn.Module, prefix: str) -> Optional["PQLinearMethod"]:
         if isinstance(layer, LinearBase):
@@ -181,6 +187,11 @@ class PQLinearMethod(LinearMethodBase):
             layer.pq_dequant_route = ops.gemm_kernel_name(
                 64, N, G, M, K, d, layer.codes.element_size(), layer.codebooks.dtype, parts or [N],
                 packed=layer.pq_packed_codes is not None) == "generic"
+            if (layer.pq_packed_codes is not None and self.quant_config.release_reference_codes
+                    and not isinstance(self, PQEmbeddingMethod)):
+                # a one-element tensor expanded to the old shape: what the operator layer reads of it (shape, dtype,
+                # device) stays, the bytes go; the embedding method keeps its codes (pq_embedding reads them)
+                layer.codes.data = torch.zeros(1, dtype=layer.codes.dtype, device=layer.codes.device).expand(layer.codes.shape)
             if layer.pq_packed_codes is not None:
                 # scratch for the K-split launches (long-K layers, up to 128 tokens): fixed-size buffers per
                 # device, created here, at load time, when a layer can use them at any batch size
