@@ -49,7 +49,8 @@ constexpr int stream_reduce_frags(int fr) { return fr <= 8 ? fr : fr % 8 == 0 ? 
 // fragments are rows of the gate partition, the other NF/2 the same rows of the up partition, both codebooks
 // sit in the LDS image, and the epilogue stores y[t][n] = silu(gate[t][n]) * up[t][n], n < act_rows -- each
 // factor rounded to the act dtype first, exactly as the unfused GEMM followed by silu_and_mul rounds them.
-template <typename AT, typename CodeT, int D, int M, int NF, int TF, bool PACKED, int ABL = 0, bool ACT = false>
+// COALT: the activations are loaded with the lanes along the rows and placed through LDS (packed layout, from 16 tokens on)
+template <typename AT, typename CodeT, int D, int M, int NF, int TF, bool PACKED, int ABL = 0, bool ACT = false, bool COALT = false>
 __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
     const uint16_t *__restrict__ x, int T, int64_t x_stride, const void *__restrict__ codes_v,
     const uint16_t *__restrict__ codebooks, const uint16_t *__restrict__ scales, const uint16_t *__restrict__ bias,
@@ -115,6 +116,34 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
         xrow[j] = x + (size_t)(t < T ? t : T - 1) * x_stride;
     }
 
+    // Packed layout: the activations are LOADED with the lanes along the rows -- lane l takes 16-byte piece (l & 3) of
+    // token (l >> 2) of a k-step, so every quad of lanes reads 64 contiguous bytes; loaded in the operand's own shape
+    // (lane (q, c) = token c, k-octet q: the four lanes of a quad on four rows) the memory pipeline takes a wave-load
+    // at well under half the rate (tools/ingest_lab.hip) -- and turned into the MFMA operand through a KiB of LDS per
+    // register of the wave's own (place_x): written at slot u(token, piece), read back at u(c, q).  u is chosen so that
+    // neither the 8-lane groups of the write nor the 16-lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, ...) meet
+    // on a bank: u = c0 + 2 q0 + 4 (q1 ^ c1) + 8 c3 + 16 (c2 + 2 c1).
+    // Taken from 16 tokens on (COALT, the launcher's choice): below, the round trip through LDS costs a launch of few
+    // tokens more than the loads save (measured: 4 - 9 % slower at 1 - 8 tokens, 3 - 11 % faster at 16 - 256).
+    constexpr bool COAL = COALT && PACKED && !ACT && !(ABL & 8);
+    auto x_slot = [](int c, int qq) {
+        return (uint32_t)((c & 1) + 2 * (qq & 1) + 4 * (((qq >> 1) ^ (c >> 1)) & 1) + 8 * ((c >> 3) & 1) +
+                          16 * (((c >> 2) & 1) + 2 * ((c >> 1) & 1)));
+    };
+    const int lt = lane >> 2, lp = lane & 3;
+    bool ltok_ok[TF];
+    const uint16_t *lrow[TF];
+#pragma unroll
+    for (int j = 0; j < TF; ++j) {
+        const int t = t0 + 16 * j + lt;
+        ltok_ok[j] = t < T;
+        lrow[j] = x + (size_t)(t < T ? t : T - 1) * x_stride;
+    }
+    // the wave's KiB slots lie behind the codebook image and the reduction area
+    const uint32_t x_lds_off = COAL ? stream_x_lds_offset((size_t)M * K * EB * R, (size_t)ST_WAVES * RF * 64 * 16) : 0u;
+    unsigned char *x_lds = smem + x_lds_off + (size_t)wave * (SUBK * TF * 1024);
+    const uint32_t x_wr = x_slot(lt, lp) * 16u, x_rd = x_slot(r16, q) * 16u;
+
     struct Codes { u32x4 cw[NF]; };
     struct XSub { vec8 f[SUBK][TF]; };
 
@@ -144,24 +173,39 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
             }
         }
     };
-    // activation fragments of k-steps sub*SUBK .. +SUBK-1 of chunk c
+    // activation fragments of k-steps sub*SUBK .. +SUBK-1 of chunk c (COAL: as loaded, place_x makes operands of them)
     auto load_x = [&](XSub &xs, int c, int sub) {
 #pragma unroll
         for (int s = 0; s < SUBK; ++s) {
             int k;
-            if constexpr (PACKED) k = c * (CG * D) + 32 * (sub * SUBK + s) + 8 * q;   // 32 consecutive k per step
+            if constexpr (PACKED) k = c * (CG * D) + 32 * (sub * SUBK + s) + 8 * (COAL ? lp : q);   // 32 consecutive k per step (compile-time choice)
             else k = (c * CG + GPL * q) * D + 8 * (sub * SUBK + s);                 // the lane's own 16 groups
             const bool k_ok = k < Kin;
 #pragma unroll
             for (int j = 0; j < TF; ++j) {
                 u32x4 v;
                 if constexpr (ABL & 8) v = u32x4{(uint32_t)k, 1u, 2u, (uint32_t)lane};
-                else v = *reinterpret_cast<const u32x4 *>(xrow[j] + (k_ok ? k : 0));
+                else v = *reinterpret_cast<const u32x4 *>((COAL ? lrow[j] : xrow[j]) + (k_ok ? k : 0));
                 // zeroing by mask, not by select: a select lets the compiler sink the load into a branch
-                const uint32_t keep = 0u - (uint32_t)(k_ok && tok_ok[j]);
+                const uint32_t keep = 0u - (uint32_t)(k_ok && (COAL ? ltok_ok[j] : tok_ok[j]));
                 v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
                 xs.f[s][j] = __builtin_bit_cast(vec8, v);
             }
+        }
+    };
+    // COAL: loaded registers -> MFMA operands, through the wave's LDS slots (a wave's LDS accesses execute in order)
+    auto place_x = [&](XSub &xs) {
+        if constexpr (COAL) {
+#pragma unroll
+            for (int s = 0; s < SUBK; ++s)
+#pragma unroll
+                for (int j = 0; j < TF; ++j)
+                    *reinterpret_cast<u32x4 *>(x_lds + (s * TF + j) * 1024 + x_wr) = __builtin_bit_cast(u32x4, xs.f[s][j]);
+#pragma unroll
+            for (int s = 0; s < SUBK; ++s)
+#pragma unroll
+                for (int j = 0; j < TF; ++j)
+                    xs.f[s][j] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4 *>(x_lds + (s * TF + j) * 1024 + x_rd));
         }
     };
 
@@ -263,6 +307,7 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
         for (int sub = 0; sub < NSUB; ++sub) {
             if (sub + 1 < NSUB) load_x(X[(sub + 1) & 1], c, sub + 1);
             else if (m1) load_x(X[(sub + 1) & 1], c1, 0);
+            place_x(X[sub & 1]);
             compute_sub(cA, X[sub & 1], sub);
         }
         if (m1) {
@@ -271,6 +316,7 @@ __global__ __launch_bounds__(ST_THREADS) void gemm_stream_kernel(
             for (int sub = 0; sub < NSUB; ++sub) {
                 if (sub + 1 < NSUB) load_x(X[(NSUB + sub + 1) & 1], c1, sub + 1);
                 else if (m2) load_x(X[(NSUB + sub + 1) & 1], c2, 0);
+                place_x(X[(NSUB + sub) & 1]);
                 compute_sub(cB, X[(NSUB + sub) & 1], sub);
             }
         }
@@ -437,15 +483,36 @@ static hipError_t launch_nf(const GemmArgs &a, int ksplit, hipStream_t stream) {
     size_t lds = (size_t)a.M * a.K * 2 * D * R;
     const size_t red = (size_t)ST_WAVES * RF * 64 * 16;
     if (red > lds) lds = red;
+    typedef void (*kern_t)(const uint16_t *, int, int64_t, const void *, const uint16_t *, const uint16_t *, const uint16_t *,
+                           TileMap, int, int, int, int, uint16_t *, int64_t, int, float *, unsigned *, int);
+    kern_t kern = gemm_stream_kernel<AT, CodeT, D, M, NF, TF, PACKED>;
+    if constexpr (PACKED) {
+        if (a.T >= 16) {
+            // lanes along the rows + placement through the waves' activation slots (a KiB per operand register in
+            // flight: 8 KiB per wave) behind image and reduction area
+            kern = gemm_stream_kernel<AT, CodeT, D, M, NF, TF, PACKED, 0, false, true>;
+            constexpr int KS_ = StreamFmt<sizeof(CodeT), D, M>::KS, SUBK_ = (8 / TF) < KS_ ? (8 / TF) : KS_;
+            lds = stream_x_lds_offset((size_t)a.M * a.K * 2 * D * R, red) + (size_t)ST_WAVES * SUBK_ * TF * 1024;
+            static std::atomic<bool> attr_set[64];   // per device: more than the default 64 KiB of dynamic LDS
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+            if (!attr_set[dev].load(std::memory_order_acquire)) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)(2 * ST_MAX_LDS_CB));
+                if (e != hipSuccess) return e;
+                attr_set[dev].store(true, std::memory_order_release);
+            }
+        }
+    }
     const int n_tiles = tiles_in(a.parts, NF * 16);
     const dim3 grid(n_tiles * ksplit, (a.T + 16 * TF - 1) / (16 * TF));
     unsigned *ws_cnt = static_cast<unsigned *>(a.workspace);
     float *ws_part = reinterpret_cast<float *>(static_cast<unsigned char *>(a.workspace) + WS_COUNTER_BYTES);
-    hipLaunchKernelGGL((gemm_stream_kernel<AT, CodeT, D, M, NF, TF, PACKED>), grid, dim3(ST_THREADS), lds, stream,
+    hipLaunchKernelGGL(kern, grid, dim3(ST_THREADS), lds, stream,
                        static_cast<const uint16_t *>(a.x), a.T, a.x_stride, a.codes,
                        static_cast<const uint16_t *>(a.codebooks), static_cast<const uint16_t *>(a.scales),
                        static_cast<const uint16_t *>(a.bias), make_tile_map(a.parts, NF * 16), a.G, a.K, nbits, R,
-                       static_cast<uint16_t *>(a.y), a.y_stride, ksplit, ws_part, ws_cnt);
+                       static_cast<uint16_t *>(a.y), a.y_stride, ksplit, ws_part, ws_cnt, 0);
     return hipGetLastError();
 }
 

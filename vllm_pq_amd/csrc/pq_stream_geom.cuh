@@ -7,6 +7,12 @@
 namespace pq {
 
 constexpr int ST_MAX_LDS_CB = 64 * 1024;   // LDS budget of the replicated codebook image
+// LDS offset of the streaming kernel's activation slots: behind the codebook image and the reduction area (which
+// share the front of the LDS), 16-byte aligned
+__host__ __device__ inline uint32_t stream_x_lds_offset(size_t image_bytes, size_t reduce_bytes) {
+    const size_t m = image_bytes > reduce_bytes ? image_bytes : reduce_bytes;
+    return (uint32_t)((m + 15) & ~(size_t)15);
+}
 
 template <int D>
 struct StreamGeom {
