@@ -66,7 +66,9 @@ static double stream_model_us(const GemmArgs &a, int nf, int tf, int ksplit) {
     const int subk = 8 / tf < ks ? 8 / tf : ks;
     const double tall = nf > 4 ? 1.3 * (nf - 4) : 0.0;   // gathers of the fragments beyond four, per chunk
     const double fixed = stream_light_format(a) ? 4.0 : 7.0;   // measured: 3 us more for d < 8, two-byte codes, M = 2
-    return rounds * (fixed + (ksplit > 1 ? 2.0 : 0.0) + per_wave * ((ks / subk) * 1.9 + tall));   // + 2 us: partial sums, count, re-read
+    // (from 16 tokens on the packed layout's activation loads run with the lanes along the rows: 1.55 us per sub-load)
+    const double sub_us = a.packed && a.T >= 16 ? 1.55 : 1.9;
+    return rounds * (fixed + (ksplit > 1 ? 2.0 : 0.0) + per_wave * ((ks / subk) * sub_us + tall));   // + 2 us: partial sums, count, re-read
 }
 
 // The same for blocks of one token fragment (TF = 1) and NF weight fragments: 5.3 us fixed (3.8 when a short K
@@ -83,7 +85,8 @@ static double stream_tall_model_us(const GemmArgs &a, int nf, int ksplit) {
     const double per_wave = nchunks / 8.0 < 1.0 ? 1.0 : nchunks / 8.0;
     const int nsub = ks > 8 ? ks / 8 : 1;   // sub-loads per chunk at TF = 1
     const double scale = ks / 16.0;
-    const double chunks_us = scale * (1.0 + 0.5 * nf) + (per_wave - 1.0) * (1.55 * nsub + scale * 0.2 * nf);
+    const double ld = a.packed && a.T >= 16 ? 0.85 : 1.0;   // activation loads with the lanes along the rows
+    const double chunks_us = scale * (1.0 * ld + 0.5 * nf) + (per_wave - 1.0) * (1.55 * ld * nsub + scale * 0.2 * nf);
     const double busy = nchunks / 8.0 < 1.0 ? nchunks / 8.0 : 1.0;   // waves of a block that have a chunk at all
     return rounds * (3.3 + 2.0 * busy + (ksplit > 1 ? 2.0 : 0.0) + chunks_us);
 }
