@@ -93,7 +93,7 @@ LAUNCH_LOG = None
 
 
 def enable_launch_log(stack, dtype):
-    """Wraps the operator layer's three GEMM entry points (every PQ GEMM launch of the process goes through one of
+    """Wraps the operator layer's GEMM entry points (every PQ GEMM launch of the process goes through one of
     them, whichever plugin method issued it), so the log holds exactly one record per kernel dispatch."""
     global LAUNCH_LOG
     from vllm_pq_amd import ops
@@ -136,6 +136,13 @@ def enable_launch_log(stack, dtype):
 
     ops.pq_gemm, ops.pq_gemm_packed, ops.pq_gemm_packed_silu_mul = gemm, gemm_packed, gemm_packed_silu_mul
     ops.pq_gemm_packed_add_norm, ops.pq_gemm_packed_normed = gemm_packed_add_norm, gemm_packed_normed
+    normed_act = ops.pq_gemm_packed_normed_silu_mul
+
+    def gemm_packed_normed_silu_mul(xw, ssq, eps, packed_codes, codes, codebooks, scales, bias):
+        record(xw, codes, codebooks, [codes.shape[0] // 2] * 2, True, fused="+normed+silu_mul")
+        return normed_act(xw, ssq, eps, packed_codes, codes, codebooks, scales, bias)
+
+    ops.pq_gemm_packed_normed_silu_mul = gemm_packed_normed_silu_mul
 
 
 class Graph:
@@ -382,15 +389,12 @@ def layer_chain(stack, T, device, dtype, cfg=LLAMA3_8B, reps=5):
                   qm.norm_pair_supported(b["down_proj"], b["qkv_proj"], T) for b in stack[:1])
 
     def step_fused():
-        from vllm_pq_amd import ops
         h, res = x0.clone(), x0.clone()
         h, res = norms[0][0](h, res)
         qkv, _ = stack[0]["qkv_proj"](h)
         for i, (blk, (n1, n2)) in enumerate(zip(stack, norms)):
             xw, ssq = qm.apply_add_norm(blk["o_proj"], qkv[:, :q], res, n2.weight.data)
-            gu = qm.apply_normed(blk["gate_up_proj"], xw, ssq, 1e-5)
-            a = torch.empty(gu.shape[:-1] + (gu.shape[-1] // 2,), dtype=gu.dtype, device=gu.device)
-            ops.silu_and_mul(a, gu)
+            a = qm.apply_normed_silu_and_mul(blk["gate_up_proj"], xw, ssq, 1e-5)
             if i + 1 < len(stack):
                 xw, ssq = qm.apply_add_norm(blk["down_proj"], a, res, norms[i + 1][0].weight.data)
                 qkv = qm.apply_normed(stack[i + 1]["qkv_proj"], xw, ssq, 1e-5)
@@ -418,7 +422,7 @@ def layer_chain(stack, T, device, dtype, cfg=LLAMA3_8B, reps=5):
     if fusable:
         fused = timed(step_fused)
         return {"ms": fused, "ms_separate_norms": separate, "layers": len(stack), "launch": "hipgraph",
-                "steps_per_layer": ["o_proj+add (+ sum of squares)", "gate_up_proj (x 1/rms)", "silu_and_mul",
+                "steps_per_layer": ["o_proj+add (+ sum of squares)", "gate_up_proj (x 1/rms) + silu_and_mul",
                                     "down_proj+add (+ sum of squares)", "next qkv_proj (x 1/rms)"],
                 "steps_per_layer_separate": ["fused_add_rms_norm", "qkv_proj", "o_proj", "fused_add_rms_norm",
                                              "gate_up_proj+silu_and_mul", "down_proj"]}

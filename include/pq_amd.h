@@ -271,6 +271,19 @@ int pq_gemm_packed_normed(const void *xw, int32_t T, int64_t xw_row_stride, cons
                           int64_t y_row_stride, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * pq_gemm_packed_normed for a gate_up layer with its activation: y [T][I] = silu(g) * u with [g | u] =
+ * pq_gemm_packed_normed(xw, ...) of the layer's two equal partitions {I, I}; bit-identical to pq_gemm_packed_normed
+ * followed by pq_silu_and_mul.  Runs where the decode kernel fuses the activation (K = 256 entries, in_features up to
+ * 4096, at most 128 tokens): the _supported() query says so.  No reference counterpart as one operator.
+ */
+int pq_gemm_packed_normed_silu_mul_supported(int32_t T, int32_t I, int32_t G, int32_t K, int32_t d, int32_t code_bytes,
+                                             int32_t dtype);
+int pq_gemm_packed_normed_silu_mul(const void *xw, int32_t T, int64_t xw_row_stride, const void *packed_codes,
+                                   const void *codebooks, const void *scales, const void *bias /* nullable */, int32_t I,
+                                   int32_t G, int32_t K, int32_t d, int32_t code_bytes, int32_t dtype, const float *ssq,
+                                   float eps, void *y, int64_t y_row_stride, void *stream);
+
+/*
  * Small-message all-reduce (SUM) between the tensor-parallel ranks of one node, one process per GPU, over device
  * buffers the ranks map into each other (IPC handles; xGMI carries the loads and stores): the sum a row-parallel
  * PQ linear needs behind its GEMM (vllm/model_executor/layers/linear.py:1206-1213) at decode batch sizes.  It

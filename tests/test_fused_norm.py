@@ -129,3 +129,61 @@ def test_norm_pair_supported_through_the_method():
     assert (res.float() - want_res.float()).abs().max() <= 2.0 ** -7 * want_res.float().abs().max()
     y = m.apply_normed(gu, xw, ssq, 1e-5)
     assert y.shape == (5, 1024) and torch.isfinite(y).all()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("T,H,I,bias", [(1, 1024, 1536, False), (7, 1024, 176, True), (16, 4096, 14336, False),
+                                        (3, 4096, 14336, True), (40, 1536, 512, True), (128, 512, 1024, False),
+                                        (16, 2048, 48, False)])
+def test_normed_gate_up_with_activation(dtype, T, H, I, bias):
+    """pq_gemm_packed_normed_silu_mul against pq_gemm_packed_normed followed by silu_and_mul: bit for bit (the same
+    kernel, the same order of sums -- a layer of at most 4096 inputs is never split along K -- the same roundings)."""
+    from vllm_pq_amd import ops
+    if dtype == "fp16" and H == 4096:
+        pytest.skip("full-size case once")
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    p = _layer(6000 + T, [I, I], H, dtype, bias)
+    pk = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, [I, I])
+    g = torch.Generator(device="cpu").manual_seed(6100 + T)
+    xw = torch.randn(T, H, generator=g).to(tdt).to(DEV)
+    Tp = (T + 15) // 16 * 16
+    ssq = (torch.rand(H // 16, Tp, generator=g) * 16 + 4).to(DEV)
+    assert ops.gemm_normed_supported(T, p.codes_dev, p.codebooks_dev, [I, I])
+    assert ops.gemm_normed_silu_mul_supported(T, p.codes_dev, p.codebooks_dev)
+    y = ops.pq_gemm_packed_normed(xw, ssq, EPS, pk, p.codes_dev, p.codebooks_dev, p.scales_dev, [I, I], p.bias_dev)
+    want = torch.empty(T, I, dtype=tdt, device=DEV)
+    ops.silu_and_mul(want, y)
+    got = ops.pq_gemm_packed_normed_silu_mul(xw, ssq, EPS, pk, p.codes_dev, p.codebooks_dev, p.scales_dev, p.bias_dev)
+    assert got.shape == (T, I)
+    gb, wb = got.view(torch.int16), want.view(torch.int16)          # bit patterns: NaN (inf * 0 in fp16) compares too
+    assert torch.equal(gb, wb), f"{int((gb != wb).sum())} of {got.numel()} values differ"
+
+
+def test_normed_gate_up_with_activation_limits():
+    """Not for more than 128 tokens, codebooks of other sizes, or layers of more than 4096 inputs; the method falls back
+    to the two steps there."""
+    from vllm_pq_amd import ops, PQConfig
+    from vllm_pq_amd.host.linear import MergedColumnParallelLinear
+    p = _layer(6500, [256, 256], 1024, "bf16", False)
+    assert ops.gemm_normed_silu_mul_supported(128, p.codes_dev, p.codebooks_dev)
+    assert not ops.gemm_normed_silu_mul_supported(129, p.codes_dev, p.codebooks_dev)
+    p16 = Problem(6501, 16, 8, 1, [256, 256], 1024, 1, "bf16").to(DEV)
+    assert not ops.gemm_normed_silu_mul_supported(4, p16.codes_dev, p16.codebooks_dev)
+    big = _layer(6502, [64, 64], 8192, "bf16", False)
+    assert not ops.gemm_normed_silu_mul_supported(4, big.codes_dev, big.codebooks_dev)
+    # through the method, on a layer the library fuses and on one it does not (16 entries)
+    for prob, K_bits in ((p, 8), (p16, 4)):
+        layer = MergedColumnParallelLinear(1024, [256, 256], bias=False, params_dtype=torch.bfloat16,
+                                           quant_config=PQConfig(8, K_bits, 1, 1))
+        layer.codes.data, layer.codebooks.data, layer.scales.data = prob.codes, prob.codebooks, prob.scales
+        layer.to(DEV)
+        m = layer.quant_method
+        m.process_weights_after_loading(layer)
+        xw = torch.randn(5, 1024, device=DEV).to(torch.bfloat16)
+        ssq = torch.rand(64, 16, device=DEV) * 16 + 4
+        if not ops.gemm_normed_supported(5, layer.codes, layer.codebooks, [256, 256]):
+            continue
+        y = m.apply_normed(layer, xw, ssq, EPS)
+        want = torch.empty(5, 256, dtype=torch.bfloat16, device=DEV)
+        ops.silu_and_mul(want, y)
+        assert torch.equal(m.apply_normed_silu_and_mul(layer, xw, ssq, EPS).view(torch.int16), want.view(torch.int16))

@@ -21,7 +21,8 @@ EXPORTS = ("pq_version", "pq_caps", "pq_last_error", "pq_dequant", "pq_gemm_work
            "pq_debug_reload_knobs", "pq_gemm_workspace_max_bytes", "pq_gemm_packed_noalloc", "pq_ar_last_error", "pq_ar_buffer_bytes",
            "pq_ar_max_message_bytes", "pq_ar_alloc", "pq_ar_free", "pq_ar_open", "pq_ar_close", "pq_ar_create",
            "pq_ar_destroy", "pq_ar_all_reduce", "pq_ar_status", "pq_gemm_packed_add_norm_supported",
-           "pq_gemm_packed_normed_supported", "pq_gemm_packed_add_norm", "pq_gemm_packed_normed")
+           "pq_gemm_packed_normed_supported", "pq_gemm_packed_add_norm", "pq_gemm_packed_normed",
+           "pq_gemm_packed_normed_silu_mul_supported", "pq_gemm_packed_normed_silu_mul")
 
 _lock = threading.Lock()
 _lib = None
@@ -100,6 +101,11 @@ def load():
         L.pq_gemm_packed_normed.argtypes = [vp, i32, i64, vp, vp, vp, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32,
                                             vp, f32, vp, i64, vp, sz, vp]
         L.pq_gemm_packed_normed.restype = ctypes.c_int
+        L.pq_gemm_packed_normed_silu_mul_supported.argtypes = [i32] * 7
+        L.pq_gemm_packed_normed_silu_mul_supported.restype = ctypes.c_int
+        L.pq_gemm_packed_normed_silu_mul.argtypes = [vp, i32, i64, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp,
+                                                     ctypes.c_float, vp, i64, vp]
+        L.pq_gemm_packed_normed_silu_mul.restype = ctypes.c_int
         L.pq_debug_reload_knobs.argtypes = []
         L.pq_debug_reload_knobs.restype = None
         pvp = ctypes.POINTER(vp)

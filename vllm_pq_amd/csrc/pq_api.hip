@@ -425,6 +425,10 @@ int pq_gemm_silu_mul_is_fused(int32_t T, int32_t I, int32_t G, int32_t K, int32_
     return pq::packable(a.parts, G, d, K, 1, code_bytes) && pq::gemm_stream_act_supported(a) ? 1 : 0;
 }
 
+// The decode kernel's fused launch where it takes the problem (at most 16 tokens here: the entry's fused range), else
+// the streaming kernel's.
+static bool decode_act_taken(const pq::GemmArgs &a) { return a.T <= 16 && pq::gemm_decode_act_supported(a); }
+
 int pq_gemm_packed_silu_mul(const void *x, int32_t T, int64_t x_row_stride, const void *packed_codes,
                             const void *codebooks, const void *scales, const void *bias, int32_t I, int32_t G,
                             int32_t K, int32_t d, int32_t code_bytes, int32_t dtype, void *y, int64_t y_row_stride,
@@ -440,7 +444,7 @@ int pq_gemm_packed_silu_mul(const void *x, int32_t T, int64_t x_row_stride, cons
         return fail(PQ_ERR_UNSUPPORTED, "%s: this format has no packed layout (pq_packed_codes_bytes() == 0)", fn);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (pq::gemm_stream_act_supported(a)) {
-        hipError_t e = pq::launch_gemm_stream_act(a, s);
+        hipError_t e = decode_act_taken(a) ? pq::launch_gemm_decode_act(a, s) : pq::launch_gemm_stream_act(a, s);
         if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "%s: %s", fn, hipGetErrorString(e));
         return PQ_OK;
     }
@@ -527,6 +531,39 @@ int pq_gemm_packed_normed(const void *xw, int32_t T, int64_t xw_row_stride, cons
     pq::NormFuse nf{2, nullptr, 0, nullptr, nullptr, 0, const_cast<float *>(ssq), G * d, eps};
     return norm_common(fn, nf, xw, T, xw_row_stride, packed_codes, codebooks, scales, bias, part_sizes, num_parts, N, G, M,
                        K, d, code_bytes, dtype, y, y_row_stride, workspace, workspace_bytes, stream, false);
+}
+
+int pq_gemm_packed_normed_silu_mul_supported(int32_t T, int32_t I, int32_t G, int32_t K, int32_t d, int32_t code_bytes,
+                                             int32_t dtype) {
+    pq::GemmArgs a;
+    void *al = reinterpret_cast<void *>(uintptr_t(256));
+    if (fill_gate_up(a, "pq_gemm_packed_normed_silu_mul", al, T, (int64_t)G * d, al, al, al, nullptr, I, G, K, d,
+                     code_bytes, dtype, al, I))
+        return 0;
+    if (T == 0 || I == 0) return 0;
+    pq::NormFuse nf{2, nullptr, 0, nullptr, nullptr, 0, static_cast<float *>(al), G * d, 1e-5f};
+    a.norm = &nf;
+    return pq::packable(a.parts, G, d, K, 1, code_bytes) && pq::gemm_decode_act_supported(a) ? 1 : 0;
+}
+
+int pq_gemm_packed_normed_silu_mul(const void *xw, int32_t T, int64_t xw_row_stride, const void *packed_codes,
+                                   const void *codebooks, const void *scales, const void *bias, int32_t I, int32_t G,
+                                   int32_t K, int32_t d, int32_t code_bytes, int32_t dtype, const float *ssq, float eps,
+                                   void *y, int64_t y_row_stride, void *stream) {
+    const char *fn = "pq_gemm_packed_normed_silu_mul";
+    pq::GemmArgs a;
+    int rc = fill_gate_up(a, fn, xw, T, xw_row_stride, packed_codes, codebooks, scales, bias, I, G, K, d, code_bytes,
+                          dtype, y, y_row_stride);
+    if (rc) return rc;
+    if (T == 0 || I == 0) return PQ_OK;
+    if (!y || !scales || !xw || !packed_codes || !codebooks || !ssq) return fail(PQ_ERR_INVALID_ARGUMENT, "%s: NULL tensor pointer", fn);
+    pq::NormFuse nf{2, nullptr, 0, nullptr, nullptr, 0, const_cast<float *>(ssq), G * d, eps};
+    a.norm = &nf;
+    if (!pq::packable(a.parts, G, d, K, 1, code_bytes) || !pq::gemm_decode_act_supported(a))
+        return fail(PQ_ERR_UNSUPPORTED, "%s: not a problem the decode kernel fuses (see %s_supported())", fn, fn);
+    hipError_t e = pq::launch_gemm_decode_act(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "%s: %s", fn, hipGetErrorString(e));
+    return PQ_OK;
 }
 
 }  // extern "C"

@@ -119,8 +119,10 @@ bool gemm_decode_norm_supported(const GemmArgs &a) {
 }
 
 template <typename AT>
-static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipStream_t stream) {
+static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipStream_t stream, bool act = false) {
     DecodeParams p;
+    p.act_rows = act ? a.parts.size[0] : 0;
+    p.phases = 2;
     p.residual = nullptr; p.res_stride = 0; p.norm_w = nullptr; p.xw = nullptr; p.xw_stride = 0; p.ssq = nullptr;
     p.t_pad = (a.T + 15) & ~15; p.ssq_frags = 0; p.eps = 0.f; p.inv_hidden = 0.f;
     const int role = a.norm ? a.norm->role : 0;
@@ -154,8 +156,13 @@ static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipSt
     p.ws_cnt = static_cast<unsigned *>(a.workspace);
     p.ws_part = g.ksplit > 1 ? reinterpret_cast<float *>(static_cast<unsigned char *>(a.workspace) + WS_COUNTER_BYTES) : nullptr;
     const int rows = (g.waves >> g.wk_log2) * g.nf * 16;
-    p.tmap = make_tile_map(a.parts, rows);
-    const dim3 grid(tiles_in(a.parts, rows), g.ksplit, (a.T + 15) / 16);
+    Parts tparts = a.parts;
+    if (act) {   // tiles over the gate partition; the up rows follow act_rows further on
+        tparts.num = 1;
+        for (int q = 1; q < PQ_MAX_PARTS; ++q) tparts.size[q] = 0;
+    }
+    p.tmap = make_tile_map(tparts, rows);
+    const dim3 grid(tiles_in(tparts, rows), g.ksplit, (a.T + 15) / 16);
     const size_t lds = dc_lds_bytes(g.waves, p.img_bytes);
     auto launch = [&](auto kern) -> hipError_t {
         static std::atomic<bool> attr_set[64];   // per device: more than the default 64 KiB of LDS
@@ -170,9 +177,53 @@ static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipSt
         hipLaunchKernelGGL(kern, grid, dim3(g.waves * 64), lds, stream, p);
         return hipGetLastError();
     };
+    if (act) return role == 2 ? launch(gemm_decode_kernel<AT, false, 0, 2, true>) : launch(gemm_decode_kernel<AT, false, 0, 0, true>);
     if (role == 1) return launch(gemm_decode_kernel<AT, false, 0, 1>);
     if (role == 2) return launch(gemm_decode_kernel<AT, false, 0, 2>);
     return launch(gemm_decode_kernel<AT>);
+}
+
+// Geometry of the fused gate_up + activation launch: 8 waves, as many along K as there are chunks, nf gate fragments
+// (and as many up fragments) per wave with the fewest rounds of one block per CU.
+static DecodeGeom choose_decode_act_geom(const GemmArgs &a) {
+    DecodeGeom g{0, 0, 1, 0, 1, 0};
+    const int nchunks = a.G / 64;
+    if (nchunks < 1 || nchunks > DC_MAX_WAVES) return g;
+    g.cpb = nchunks;
+    g.wk_log2 = nchunks >= 5 ? 3 : nchunks >= 3 ? 2 : nchunks >= 2 ? 1 : 0;
+    const int WK = 1 << g.wk_log2, wr = DC_MAX_WAVES / WK;
+    g.waves = DC_MAX_WAVES;
+    Parts gate;
+    gate.num = 1;
+    for (int q = 0; q < PQ_MAX_PARTS; ++q) gate.size[q] = q == 0 ? a.parts.size[0] : 0;
+    double best = -1.0;
+    for (int nf = 1; nf <= WK && 2 * nf <= DC_UMAX; ++nf) {
+        const long tiles = (long)tiles_in(gate, wr * nf * 16) * ((a.T + 15) / 16);
+        const double cost = (double)((tiles + 255) / 256) * (3.5 + 0.6 * nf) + (tiles < 256 ? 0.002 * (256 - tiles) : 0.0) * nf;
+        if (best < 0.0 || cost < best) { best = cost; g.nf = nf; }
+    }
+    return g;
+}
+
+bool gemm_decode_act_supported(const GemmArgs &a) {
+    if (a.parts.num != 2 || a.parts.size[0] != a.parts.size[1] || a.parts.size[0] % 16) return false;
+    if (a.K != 256 || a.G / 64 > DC_MAX_WAVES) return false;
+    GemmArgs full = a;                      // the plain kernel's format and alignment checks, on the [T][N] problem
+    full.norm = nullptr;
+    if (!gemm_decode_supported(full)) return false;
+    if (a.norm) {
+        if (a.norm->role != 2 || !a.norm->ssq || a.norm->hidden != a.G * a.d || a.norm->hidden % 16 ||
+            a.norm->hidden / 16 > 8 * (DC_MAX_WAVES * 4))
+            return false;
+    }
+    return choose_decode_act_geom(a).nf > 0;
+}
+
+hipError_t launch_gemm_decode_act(const GemmArgs &a, hipStream_t stream) {
+    if (a.N == 0 || a.T == 0) return hipSuccess;
+    if (!gemm_decode_act_supported(a)) return hipErrorInvalidValue;
+    const DecodeGeom g = choose_decode_act_geom(a);
+    return a.dtype == PQ_DTYPE_BF16 ? launch_decode_at<bf16_t>(a, g, stream, true) : launch_decode_at<fp16_t>(a, g, stream, true);
 }
 
 hipError_t launch_gemm_decode(const GemmArgs &a, hipStream_t stream) {

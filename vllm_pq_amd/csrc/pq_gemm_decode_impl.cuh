@@ -1,5 +1,6 @@
-// Fused codebook gather + MFMA GEMM for decode batches (at most 16 tokens) on gfx950: d = 8, one codebook of at
-// most 256 entries, one-byte codes in the PACKED order (pq_gemm_stream.hip).
+// Fused codebook gather + MFMA GEMM for decode batches on gfx950 (16 tokens per block; batches of up to 128 tokens run
+// as groups of 16 over gridDim.z): d = 8, one codebook of at most 256 entries, one-byte codes in the PACKED order
+// (pq_gemm_stream.hip).
 //
 // y[t][n] = scale[n] * sum_k x[t][k] * W[n][k] + bias[n],   W[n][8g..8g+7] = centroid(code[n][g])
 //
@@ -7,25 +8,29 @@
 // v_mfma_f32_16x16x32 is read straight out of the replicated LDS codebook image at the address the lane's code
 // byte selects, the activations are the B operand and stay in registers, K is split over the waves of a block
 // and the partial sums meet in LDS in a fixed order.  What differs is how the launch is built, because a decode
-// launch lasts a few microseconds and two things set its length that do not matter in a long kernel:
+// launch lasts a few microseconds and three things set its length that do not matter in a long kernel:
 //
 //  * Instruction fetch.  Every launch starts with a cold instruction cache, and straight-line code that is
 //    executed once runs at the rate the cache fills (measured: 12.5 cycles per 8-byte instruction cold against
 //    5 warm with 8 waves per CU), so 1 KiB of code that is executed once costs about 0.7 us.  This kernel is
 //    a few short loops: a unit (one 16-row fragment x one 512-feature chunk: 16 gathers + 16 MFMAs) is ONE loop
 //    body, whatever the tile shape; tile shape, waves per block and K split are run-time values.
-//  * Requests first.  The codes never pass through registers: every wave sends all its units' code pieces
-//    (1 KiB each) from HBM straight into an LDS staging area by LDS-DMA before it computes anything, so the
-//    whole HBM stream of the launch is requested in its first microsecond; a unit is computed when its piece has
-//    landed (loads return in order; the wait is a counted vmcnt).  A unit's accumulator lives in the staging
-//    slot its codes came in, so the loop body does not depend on the fragment either.
+//  * The shape of the activation loads.  Every block reads its K range of all 16 tokens; the memory pipeline takes a
+//    wave-load whose quads of lanes each read 64 contiguous bytes four times faster than one shaped like the MFMA
+//    operand (four rows per quad).  The activations come in as one contiguous KiB per token by LDS-DMA and are read
+//    into the operand registers from LDS (see the kernel body).
+//  * The order of the requests.  A CU returns memory data in request order across all its waves, so the code
+//    pieces (HBM) are requested only when every wave's activations (L2) have landed; they never pass through
+//    registers: every wave sends its units' pieces (1 KiB each) straight into an LDS staging area by LDS-DMA, and a
+//    unit is computed when its piece has landed (the wait is a counted vmcnt).  A unit's accumulator lives in the
+//    staging slot its codes came in, so the loop body does not depend on the fragment either.
 //
-// Work split: a block of WK x WR waves owns WR * nf fragments (16 rows each) of one output partition and all of
-// K (at most 8 chunks of 512 features: K <= 4096); wave (wk, wr) takes chunk wk of fragments wr * nf .. + nf - 1.
-// The activations of the chunk (16 x 16 bytes per lane) are loaded once and reused by the nf fragments.
-// Every block reads all of x: 16 tokens x K x 2 bytes at the 55-65 GB/s a CU takes from L2, 2 us at K = 4096 --
-// the largest single cost of the launch, and why longer K goes to the streaming kernel, which splits K over blocks.
+// Work split: a block of WK x WR waves owns WR * nf fragments (16 rows each) of one output partition and at most 8
+// chunks of 512 features; wave (wk, wr) takes chunk wk of fragments wr * nf .. + nf - 1.  A longer K is split over
+// gridDim.y blocks per tile, whose fp32 partial sums meet in the caller's workspace (the streaming kernel's
+// protocol).  The activations of the chunk (16 x 16 bytes per lane) are read once and reused by the nf fragments.
 #pragma once
+#include <type_traits>
 #include "pq_common.cuh"
 #include "pq_kernels.h"
 
@@ -82,6 +87,11 @@ struct DecodeParams {
     // MODE 2 (the GEMM behind it): x holds r * norm_w; y is multiplied by rsqrt(sum of r^2 / hidden + eps) per token
     int ssq_frags;                 // fragments summed per token (hidden / 16)
     float eps, inv_hidden;
+    // ACT (gate_up_proj with its activation): the layer is two equal partitions of act_rows rows (gate, up); tmap
+    // covers the gate partition; a wave takes nf gate fragments and then the same rows' nf up fragments (2 nf units),
+    // and y [T][act_rows] = silu(gate) * up.  `phases` is 2 (a run-time value, so that the phase loop stays a loop).
+    int act_rows;
+    int phases;
     TileMap tmap;                  // tiles of (blockDim/64 >> wk_log2) * nf * 16 rows
 };
 
@@ -147,7 +157,10 @@ __device__ __forceinline__ void dc_wait_vm(int n) {
 // STAMPS (diagnostic builds only): thread 0 writes wall-clock stamps of the phases to `bias` (8 x u64 per block)
 // ABL (diagnostic builds only; 0 in the library): bit 0 leaves the MFMAs of the units out, bit 1 the gathers
 // MODE: 0 the plain linear; 1 and 2 the two halves of a fused add + RMSNorm between two linears (DecodeParams)
-template <typename AT, bool STAMPS = false, int ABL = 0, int MODE = 0>
+// ACT: gate_up_proj with SiLU-and-mul in the epilogue (DecodeParams; MODE 0 or 2; K = 256 entries, 8 waves, no K split):
+// the block computes its gate fragments with the gate codebook's image, swaps the image for the up codebook's and
+// computes the same rows' up fragments -- one codebook image at a time is all the LDS holds
+template <typename AT, bool STAMPS = false, int ABL = 0, int MODE = 0, bool ACT = false>
 __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const DecodeParams p) {
     typedef typename Act<AT>::vec8 vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -189,7 +202,8 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     const int chunk0 = (int)blockIdx.y * p.cpb;               // first chunk of this block's K range
     const int nck_blk = p.nchunks - chunk0 < p.cpb ? p.nchunks - chunk0 : p.cpb;   // chunks in it (at least one)
     const int nck = wk < nck_blk ? 1 : 0;                     // a wave beyond the last chunk has no work
-    const int U = nck * nf;                                   // its units (at most DC_UMAX)
+    const int NU = ACT ? 2 * nf : nf;                         // units of a wave with a chunk (at most DC_UMAX)
+    const int U = nck * NU;
 
     // ---- the block's tile
     const int frags_blk = (int)((blockDim.x >> 6) >> p.wk_log2) * nf;
@@ -215,6 +229,11 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
         cbv3 = dc_gload16<16>((uint32_t)(e0 + (ncb > 2 ? 2 : 0)) * 16u, cb_part);
         issued += 4;
     } else {
+        ++issued;
+    }
+    u32x4 cbu0{0u, 0u, 0u, 0u};   // ACT: the same entry of the up partition's codebook (K = 256, 512 threads: one entry a thread)
+    if constexpr (ACT) {
+        cbu0 = dc_gload16<0>((uint32_t)e0 * 16u, cb_part + (size_t)p.K * 16);
         ++issued;
     }
 
@@ -255,21 +274,20 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     int fb = wr * nf, nvalid = nfr - fb;           // first fragment of the wave, fragments it really has
     if (nvalid < 1) { fb = nfr - 1; nvalid = 1; }
     const size_t frag_bytes = (size_t)p.nchunks * 1024;
-    const unsigned char *dma_src = p.codes + ((size_t)((loc.row0 >> 4) + fb) * p.nchunks + chunk0 + wk) * 1024;
-    uint32_t dma_dst = stage0;
-    int dma_i = 0;
-    auto issue_dma = [&](int j) {
+    const unsigned char *dma_base = p.codes + ((size_t)((loc.row0 >> 4) + fb) * p.nchunks + chunk0 + wk) * 1024;
+    const size_t up_bytes = ACT ? (size_t)(p.act_rows >> 4) * frag_bytes : 0;   // from a gate fragment to the same rows' up fragment
+    auto issue_dma = [&](int j) {   // unit j: fragment j (ACT: units nf .. 2 nf - 1 are the up fragments of units 0 .. nf - 1)
         if (j < U) {
-            dc_dma16(dma_dst, lane16, dma_src);
-            dma_dst += 1024;
-            ++dma_i;
-            if (dma_i < nvalid) dma_src += frag_bytes;
+            const int jj = ACT && j >= nf ? j - nf : j;
+            const size_t off = (size_t)(jj < nvalid ? jj : nvalid - 1) * frag_bytes + (ACT && j >= nf ? up_bytes : 0);
+            dc_dma16(stage0 + (uint32_t)j * 1024u, lane16, dma_base + off);
         }
     };
 
     // ---- the activations have landed (and so have the codebook entries, which are older): operand registers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dc_landed(cbv0);
+    if constexpr (ACT) dc_landed(cbu0);
     issued = 0;
     DC_STAMP(3)   // entries and activations landed
     u32x4 B0[16];
@@ -287,16 +305,37 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     }
     DC_STAMP(4)   // operands in registers
     if constexpr (MODE == 2) {
-        float ssq_part = 0.f;
+        // The token's sum over all fragments in an order that does not depend on the block's wave count (so a token's
+        // 1 / rms is the same number whatever geometry its batch size picked): the order of a block of 8 waves.  Row
+        // tid >> 4 of such a block adds fragments row, row + 32, ...; a wave adds its four rows; the epilogue adds the
+        // 8 waves' sums in order.  A block of 8 / R waves plays R of those waves per wave: its k-th load belongs to
+        // row (tid >> 4) + (k mod R) * rows of the block.
         const int fstep = (int)(blockDim.x >> 4);
+        float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             asm volatile("" : "+v"(ssq_v[j]));      // used from here on: behind the wait for the activations
-            ssq_part += ((tid >> 4) + j * fstep < p.ssq_frags) ? ssq_v[j] : 0.f;
+            v[j] = ((tid >> 4) + j * fstep < p.ssq_frags) ? ssq_v[j] : 0.f;
         }
-        ssq_part += __shfl_xor(ssq_part, 16);
-        ssq_part += __shfl_xor(ssq_part, 32);
-        if (lane < 16) reinterpret_cast<float *>(smem + p.aux_off)[wave * 16 + lane] = ssq_part;
+        float *aux = reinterpret_cast<float *>(smem + p.aux_off);
+        auto reduce = [&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = r; k < 8; k += R) s += v[k];
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                if (lane < 16) aux[(wave + r * (8 / R)) * 16 + lane] = s;
+            }
+        };
+        switch (blockDim.x >> 6) {
+        case 8: reduce(std::integral_constant<int, 1>{}); break;
+        case 4: reduce(std::integral_constant<int, 2>{}); break;
+        case 2: reduce(std::integral_constant<int, 4>{}); break;
+        default: reduce(std::integral_constant<int, 8>{}); break;
+        }
     }
     __syncthreads();   // every wave has its activations out of the LDS: image and staging may be written
     DC_STAMP(5)   // barrier
@@ -314,6 +353,13 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     ++issued;
     u32x2 biv = dc_gload8((uint32_t)out_row * 2u, bias ? bias : p.scales);   // without a bias: loaded, never used
     ++issued;
+    u32x2 scu{0u, 0u}, biu{0u, 0u};   // ACT: scales and bias of the up rows
+    if constexpr (ACT) {
+        scu = dc_gload8((uint32_t)(out_row + p.act_rows) * 2u, p.scales);
+        ++issued;
+        biu = dc_gload8((uint32_t)(out_row + p.act_rows) * 2u, bias ? bias : p.scales);
+        ++issued;
+    }
     u32x2 rsv{0u, 0u}, nwv{0u, 0u};
     if constexpr (MODE == 1) {   // the lane's four residual values (its token, its rows) and norm weights
         const int tl = (lane & 15) < T ? (lane & 15) : T - 1;
@@ -352,7 +398,7 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     }
     if (nck == 0) {   // a wave without a chunk (more waves along K than chunks) contributes zeros
 #pragma nounroll
-        for (int i = 0; i < nf; ++i)
+        for (int i = 0; i < NU; ++i)
             *reinterpret_cast<f32x4 *>(smem + p.img_bytes + ((size_t)(wave * DC_UMAX + i) * 64 + lane) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();   // the image is complete
@@ -365,10 +411,10 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     // half of a unit's k-steps run, the gathers of the other half (or of the next unit's first half) are in flight,
     // so the LDS and the matrix pipe work at the same time.  LDS reads return in order; every count below is the
     // number of reads issued behind the one waited for.
-    auto units = [&](const u32x4 (&B)[16]) {
+    auto units = [&](const u32x4 (&B)[16], int i0, int i1) {
         u32x4 a0[8], a1[8];
-        dc_wait_vm(issued - 1 - seq_dma0);
-        u32x4 cw = dc_lds_read16(stage0 + lane16);
+        dc_wait_vm(issued - 1 - (seq_dma0 + i0));
+        u32x4 cw = dc_lds_read16(stage0 + (uint32_t)i0 * 1024u + lane16);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         dc_landed(cw);
 #define DC_G(A, j, s, sel) if constexpr (ABL & 2) { A[j] = cw; asm volatile("; PQX %0" : "+v"(A[j])); } else A[j] = dc_lds_read16(__builtin_amdgcn_perm(cw[(s) >> 2], img_lane, sel));
@@ -385,11 +431,11 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     __builtin_amdgcn_sched_barrier(0);
         DC_GLO
 #pragma nounroll
-        for (int i = 0; i < nf; ++i) {
+        for (int i = i0; i < i1; ++i) {
             f32x4 acc{0.f, 0.f, 0.f, 0.f};
             DC_GHI
             // the next unit's codes (the last unit reads its own again: same counts, no branch)
-            const int in = i + 1 < nf ? i + 1 : i;
+            const int in = i + 1 < i1 ? i + 1 : i;
             dc_wait_vm(issued - 1 - (seq_dma0 + in));
             u32x4 cwn = dc_lds_read16(stage0 + (uint32_t)in * 1024u + lane16);
             // behind a0[j]: 7 - j of its set, the store of the unit before, 8 of the other set, the read above
@@ -414,11 +460,29 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
 #undef DC_MW
 #undef DC_MN
     };
-    if (nck > 0) units(B0);
+    if constexpr (ACT) {
+#pragma nounroll
+        for (int ph = 0; ph < p.phases; ++ph) {
+            if (ph) {   // every wave is past its last gather of the gate image: the up codebook takes its place
+                __syncthreads();
+                if (img_active) {
+                    const uint32_t a0 = (uint32_t)tid * 128u + ((uint32_t)(tid & 7) << 4);
+#define DC_IS(c) *reinterpret_cast<u32x4 *>(smem + (a0 ^ ((c) << 4))) = cbu0;
+                    DC_IS(0) DC_IS(1) DC_IS(2) DC_IS(3) DC_IS(4) DC_IS(5) DC_IS(6) DC_IS(7)
+#undef DC_IS
+                }
+                __syncthreads();
+            }
+            if (nck > 0) units(B0, ph * nf, ph * nf + nf);
+        }
+    } else {
+        if (nck > 0) units(B0, 0, nf);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dc_landed(scv);
     dc_landed(biv);
     if constexpr (MODE == 1) { dc_landed(rsv); dc_landed(nwv); }
+    if constexpr (ACT) { dc_landed(scu); dc_landed(biu); }
     DC_STAMP(9)   // this wave's units done
     __syncthreads();
     DC_STAMP(10)   // all waves' units done
@@ -426,12 +490,11 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     // ---- epilogue: the partial sums of the output fragment over the waves along K, in a fixed order -------------------
     const int t_out = lane & 15;
     float rinv = 1.f;
-    if constexpr (MODE == 2) {   // 1 / rms of the token: the waves' partial sums in wave order
+    if constexpr (MODE == 2) {   // 1 / rms of the token: the 8 partial sums in order
         const float *wp = reinterpret_cast<const float *>(smem + p.aux_off) + t_out;
         float ss = wp[0];
-        const int nw = (int)(blockDim.x >> 6);
 #pragma nounroll
-        for (int w = 1; w < nw; ++w) ss += wp[w * 16];
+        for (int w = 1; w < 8; ++w) ss += wp[w * 16];
         rinv = rsqrtf(ss * p.inv_hidden + p.eps);
     }
     float ss_lane = 0.f;         // MODE 1: sum of squares of this lane's four values of r
@@ -471,7 +534,40 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
             if (lane < T) p.ssq[(size_t)(out_row >> 4) * p.t_pad + tok0 + lane] = ss;
         }
     };
-    if (out_wave) {
+    if constexpr (ACT) {
+        // wave wk < nf finishes gate fragment wk and up fragment wk of its row group: y = silu(g) * u, every factor
+        // rounded to the act dtype first, exactly as the GEMM followed by silu_and_mul rounds them
+        if (out_wave) {
+            const unsigned char *slot = smem + p.img_bytes + ((size_t)((wr << p.wk_log2) * DC_UMAX + wk) * 64 + lane) * 16;
+            f32x4 sg = *reinterpret_cast<const f32x4 *>(slot), su = *reinterpret_cast<const f32x4 *>(slot + (size_t)nf * 1024);
+#pragma nounroll
+            for (int w = 1; w < WK; ++w) {
+                const f32x4 vg = *reinterpret_cast<const f32x4 *>(slot + (size_t)w * (DC_UMAX * 1024));
+                const f32x4 vu = *reinterpret_cast<const f32x4 *>(slot + (size_t)w * (DC_UMAX * 1024) + (size_t)nf * 1024);
+                sg.x += vg.x; sg.y += vg.y; sg.z += vg.z; sg.w += vg.w;
+                su.x += vu.x; su.y += vu.y; su.z += vu.z; su.w += vu.w;
+            }
+            if (t_out < T) {
+                const uint32_t sw[2] = {scv.x, scv.y}, bw[2] = {biv.x, biv.y}, swu[2] = {scu.x, scu.y}, bwu[2] = {biu.x, biu.y};
+                uint16_t h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int sh = (e & 1) * 16;
+                    const float g = (MODE == 2 ? sg[e] * rinv : sg[e]) * Act<AT>::to_f32((uint16_t)(sw[e >> 1] >> sh)) +
+                                    (bias ? Act<AT>::to_f32((uint16_t)(bw[e >> 1] >> sh)) : 0.0f);
+                    const float u = (MODE == 2 ? su[e] * rinv : su[e]) * Act<AT>::to_f32((uint16_t)(swu[e >> 1] >> sh)) +
+                                    (bias ? Act<AT>::to_f32((uint16_t)(bwu[e >> 1] >> sh)) : 0.0f);
+                    const float yg = Act<AT>::to_f32(Act<AT>::from_f32(g)), yu = Act<AT>::to_f32(Act<AT>::from_f32(u));
+                    const float sl = Act<AT>::to_f32(Act<AT>::from_f32(yg / (1.0f + expf(-yg))));
+                    h[e] = Act<AT>::from_f32(sl * yu);
+                }
+                u32x2 o2;
+                o2.x = h[0] | ((uint32_t)h[1] << 16);
+                o2.y = h[2] | ((uint32_t)h[3] << 16);
+                *reinterpret_cast<u32x2 *>(p.y + (size_t)(tok0 + t_out) * p.y_stride + out_row) = o2;
+            }
+        }
+    } else if (out_wave) {
         const unsigned char *slot = smem + p.img_bytes + ((size_t)((wr << p.wk_log2) * DC_UMAX + wk) * 64 + lane) * 16;
         f32x4 sum = *reinterpret_cast<const f32x4 *>(slot);
 #pragma nounroll

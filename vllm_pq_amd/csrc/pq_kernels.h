@@ -96,6 +96,11 @@ DecodeGeom choose_decode_geom(const GemmArgs &a);
 hipError_t launch_gemm_decode(const GemmArgs &a, hipStream_t stream);
 // Whether launch_gemm_decode takes this problem with a.norm set (role 1 or 2).
 bool gemm_decode_norm_supported(const GemmArgs &a);
+// gate_up_proj with SiLU-and-mul in the decode kernel's epilogue: a.parts = two equal partitions (gate, up), a.y is
+// [T][N / 2]; a.norm may name role 2 (the layer sits behind a fused add + RMSNorm).  supported(): what the decode
+// kernel takes, K = 256 entries, at most 8 chunks (no K split), blocks of 8 waves.
+bool gemm_decode_act_supported(const GemmArgs &a);
+hipError_t launch_gemm_decode_act(const GemmArgs &a, hipStream_t stream);
 
 // Load-time re-layout of the codes for the MFMA kernels.
 bool stream_format_supported(int d, int K, int M, int code_bytes);

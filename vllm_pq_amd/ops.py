@@ -467,6 +467,44 @@ def pq_gemm_packed_normed(xw: torch.Tensor, ssq: torch.Tensor, eps: float, packe
     return out.reshape(xw.shape[:-1] + (N,))
 
 
+def gemm_normed_silu_mul_supported(T: int, codes: torch.Tensor, codebooks: torch.Tensor) -> bool:
+    """Whether pq_gemm_packed_normed_silu_mul runs a batch of T tokens on this gate/up layer."""
+    N, G, M, K, d, parts, pa, cb = _norm_pair_args(codes, codebooks, [codes.shape[0] // 2, codes.shape[0] - codes.shape[0] // 2])
+    if M != 1 or N % 2:
+        return False
+    return bool(_lib.load().pq_gemm_packed_normed_silu_mul_supported(T, N // 2, G, K, d, cb, _DTYPE[codebooks.dtype]))
+
+
+def pq_gemm_packed_normed_silu_mul(xw: torch.Tensor, ssq: torch.Tensor, eps: float, packed_codes: torch.Tensor,
+                                   codes: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor,
+                                   bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """pq_gemm_packed_normed of a gate/up layer (two equal output partitions) with SiLU-and-mul in the same launch:
+    bit-identical to pq_gemm_packed_normed followed by silu_and_mul.  Ask gemm_normed_silu_mul_supported() first."""
+    L = _lib.load()
+    dev = _check_device(xw, ssq, packed_codes, codes, codebooks, scales, bias)
+    N, G, M, K, d, parts, pa, cb = _norm_pair_args(codes, codebooks, [codes.shape[0] // 2, codes.shape[0] - codes.shape[0] // 2])
+    I = N // 2
+    if N != 2 * I or M != 1:
+        raise ValueError("pq_gemm_packed_normed_silu_mul: two equal output partitions (gate, up) and one codebook expected")
+    x2 = _rows16(xw, G * d, "xw")
+    T = x2.shape[0]
+    if xw.dtype != codebooks.dtype or ssq.dtype != torch.float32 or tuple(ssq.shape) != (G * d // 16, (T + 15) // 16 * 16) \
+            or not ssq.is_contiguous():
+        raise ValueError("xw of the weight's dtype and ssq [in_features / 16, tokens rounded up to 16] fp32 expected")
+    if scales.numel() != N or scales.dtype != xw.dtype or (bias is not None and (bias.numel() != N or bias.dtype != xw.dtype)):
+        raise ValueError("scales (and bias) must hold one value of the activation dtype per output row")
+    out = torch.empty((T, I), dtype=xw.dtype, device=dev)
+    if T and I:
+        with torch.cuda.device(dev):
+            rc = L.pq_gemm_packed_normed_silu_mul(
+                x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, packed_codes.data_ptr(), codebooks.contiguous().data_ptr(),
+                scales.contiguous().data_ptr(), bias.contiguous().data_ptr() if bias is not None else None, I, G, K, d, cb,
+                _DTYPE[xw.dtype], ssq.data_ptr(), float(eps), out.data_ptr(), I, _stream_ptr(dev))
+        if rc:
+            _raise(rc)
+    return out.reshape(xw.shape[:-1] + (I,))
+
+
 # ---- the element-wise neighbours of the linears -------------------------------------------------
 # Same names, argument order and in-place conventions as the reference's wrappers
 # (vllm/_custom_ops.py:151-158 rms_norm / fused_add_rms_norm; torch.ops._C.silu_and_mul as called from

@@ -263,6 +263,21 @@ class PQLinearMethod(LinearMethodBase):
         return ops.pq_gemm_packed_normed(xw, ssq, eps, layer.pq_packed_codes, layer.codes, layer.codebooks, layer.scales,
                                          parts, bias)
 
+    def apply_normed_silu_and_mul(self, layer: torch.nn.Module, xw: torch.Tensor, ssq: torch.Tensor, eps: float,
+                                  bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`SiluAndMul()(self.apply_normed(layer, ...))` for a gate/up layer: the same values, in one launch where
+        the library fuses the activation into the GEMM behind the norm."""
+        parts = list(getattr(layer.codebooks, "output_partition_sizes", []))
+        tokens = xw.numel() // xw.shape[-1] if xw.shape[-1] else 0
+        if (len(parts) == 2 and parts[0] == parts[1] and layer.codes.shape[2] == 1
+                and ops.gemm_normed_silu_mul_supported(tokens, layer.codes, layer.codebooks)):
+            return ops.pq_gemm_packed_normed_silu_mul(xw, ssq, eps, layer.pq_packed_codes, layer.codes, layer.codebooks,
+                                                      layer.scales, bias)
+        y = self.apply_normed(layer, xw, ssq, eps, bias)
+        out = torch.empty(y.shape[:-1] + (y.shape[-1] // 2,), dtype=y.dtype, device=y.device)
+        ops.silu_and_mul(out, y)
+        return out
+
 
 class PQEmbeddingMethod(PQLinearMethod):
     """PQ-compressed vocabulary table: [rows of this rank, embedding_dim] as one output partition.  apply() gives
