@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--quick", action="store_true", help="model shapes only")
     ap.add_argument("--cache-mb", type=int, default=400, help="bytes of codes to rotate over")
+    ap.add_argument("--only", default="", help="comma-separated substrings: only the shapes whose name holds one")
+    ap.add_argument("--ts", default="", help="comma-separated token counts instead of the full grid")
     args = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
     grid = [(n, p, kin, 256, 8) for (n, p, kin) in MODEL_SHAPES]
@@ -101,12 +103,15 @@ def main():
             for K in (16, 256, 4096):
                 for d in (2, 4, 8):
                     grid.append((f"sq{size}.K{K}.d{d}", [size], size, K, d))
+    if args.only:
+        grid = [g for g in grid if any(k in g[0] for k in args.only.split(","))]
+    ts = [int(t) for t in args.ts.split(",")] if args.ts else TS
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     rows, w, t0 = [], {}, time.time()
     with open(args.out, "w", newline="") as f:
         wr = None
         for (name, parts, kin, K, d) in grid:
-            for T in TS:
+            for T in ts:
                 r = point(w, name, parts, kin, K, d, T, dt, args.reps, args.cache_mb * 1e6)
                 if wr is None:
                     wr = csv.DictWriter(f, fieldnames=list(r.keys()))
@@ -114,9 +119,9 @@ def main():
                 wr.writerow({k: (f"{v:.4g}" if isinstance(v, float) else v) for k, v in r.items()})
                 f.flush()
                 rows.append(r)
-            print(f"[{time.time() - t0:6.1f}s] {name:18s} " + " ".join(f"{r['frac']:.2f}" for r in rows[-len(TS):]),
+            print(f"[{time.time() - t0:6.1f}s] {name:18s} " + " ".join(f"{r['frac']:.2f}" for r in rows[-len(ts):]),
                   flush=True)
-    print("T grid:", TS)
+    print("T grid:", ts)
 
 
 if __name__ == "__main__":

@@ -54,6 +54,48 @@ __device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
     return v;
 }
 
+// The same for the 8- and 4-byte entries of the d = 4 and d = 2 formats.
+__device__ __forceinline__ u32x2 lds_read8(uint32_t addr) {
+    u32x2 v;
+    asm volatile("; PQI %0\n\tds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
+    uint32_t v;
+    asm volatile("; PQI %0\n\tds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+// A gathered weight fragment in flight: the lane's 16 operand bytes are one d = 8 entry, two d = 4 entries or four
+// d = 2 entries, each read by an instruction of its own into its part of the fragment.
+template <int D>
+struct GatherFrag;
+template <>
+struct GatherFrag<8> {
+    u32x4 v;
+    __device__ __forceinline__ void read(const uint32_t (&a)[1]) { v = lds_read16<0>(a[0]); }
+    __device__ __forceinline__ void landed() { asm volatile("; PQL %0" : "+v"(v)); }
+    __device__ __forceinline__ u32x4 value() const { return v; }
+};
+template <>
+struct GatherFrag<4> {
+    u32x2 h[2];
+    __device__ __forceinline__ void read(const uint32_t (&a)[2]) { h[0] = lds_read8(a[0]); h[1] = lds_read8(a[1]); }
+    __device__ __forceinline__ void landed() { asm volatile("; PQL %0\n\t; PQL %1" : "+v"(h[0]), "+v"(h[1])); }
+    __device__ __forceinline__ u32x4 value() const { return u32x4{h[0].x, h[0].y, h[1].x, h[1].y}; }
+};
+template <>
+struct GatherFrag<2> {
+    uint32_t w[4];
+    __device__ __forceinline__ void read(const uint32_t (&a)[4]) {
+        w[0] = lds_read4(a[0]); w[1] = lds_read4(a[1]); w[2] = lds_read4(a[2]); w[3] = lds_read4(a[3]);
+    }
+    __device__ __forceinline__ void landed() {
+        asm volatile("; PQL %0\n\t; PQL %1\n\t; PQL %2\n\t; PQL %3" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+    }
+    __device__ __forceinline__ u32x4 value() const { return u32x4{w[0], w[1], w[2], w[3]}; }
+};
+
 // LDS address of this lane's copy of the d = 8 codebook entry that code `i` of a code piece selects.  One-byte
 // codes (K <= 256) always get 16 copies, 256 bytes per entry; they are stored reduced mod K in the packed layout
 // and the image starts at a multiple of 64 KiB, so the address is the code byte dropped into bits 8..15 of the
@@ -72,23 +114,23 @@ __device__ __forceinline__ uint32_t gather_addr8(const VecT &w, int i, uint32_t 
 // first group of a k-step.  LDS reads return in order; this is the number of reads issued after the last one
 // group g's MFMAs need (its gathers and, for the first group of a k-step, that k-step's activations) and before
 // group g's wait: the n of its `s_waitcnt lgkmcnt(n)`.
-template <int NG, int NPAIR, int NKS, int WT, bool PRE = false>
-constexpr int pipe_newer(int g) {
+template <int NG, int NPAIR, int NKS, int WT, bool PRE = false, int GR = 2>
+constexpr int pipe_newer(int g) {   // GR: LDS reads per group's gathers (two fragments of 1, 2 or 4 entries)
     const int kk = g / NPAIR;
     const bool need_x = g % NPAIR == 0;
     int after = 0;          // reads issued after the last needed one so far
     if (PRE) {
         // issued by the stage before this one, in the gaps of its last group: G(0), G(1), X(0)
-        if (g == 0) after = 0; else after += 2;
-        if (NG > 1) { if (g == 1) after = 0; else after += 2; }
+        if (g == 0) after = 0; else after += GR;
+        if (NG > 1) { if (g == 1) after = 0; else after += GR; }
         if (need_x && kk == 0) after = 0; else after += WT;
     } else {
         // prologue: X(0), G(0), G(1)
-        if (g == 0) after = 0; else after += 2;        // G(0) is newer than X(0)
-        if (NG > 1) { if (g == 1) after = 0; else after += 2; }
+        if (g == 0) after = 0; else after += GR;        // G(0) is newer than X(0)
+        if (NG > 1) { if (g == 1) after = 0; else after += GR; }
     }
     for (int h = 0; h < g; ++h) {
-        if (h + 2 < NG) { if (h + 2 == g) after = 0; else after += 2; }
+        if (h + 2 < NG) { if (h + 2 == g) after = 0; else after += GR; }
         if (h % NPAIR == 0 && h / NPAIR + 1 < NKS) { if (need_x && h / NPAIR + 1 == kk) after = 0; else after += WT; }
     }
     return after;
@@ -137,8 +179,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
     constexpr int PPU = U / TPP;                     // pieces per loop step
     constexpr int SPU = U / KT;                      // ring stages per loop step
     typedef uint32_t piece_t __attribute__((ext_vector_type(PW)));
-    // hand-pipelined LDS reads in the main loop: d = 8, one codebook, fragments taken in pairs
-    constexpr bool PIPE = D == 8 && M == 1 && WN % 2 == 0 && WT % 2 == 0 && !(ABL & (8 | 16));
+    // hand-pipelined LDS reads in the main loop: one codebook, fragments taken in pairs; d = 8, and the smaller
+    // entries with one-byte codes (their images have 256 bytes per entry like d = 8's, so a gather address is the
+    // code byte dropped into the lane's offset)
+    constexpr bool PIPE = (D == 8 || CB == 1) && M == 1 && WN % 2 == 0 && WT % 2 == 0 && !(ABL & (8 | 16));
+    constexpr int GR = 2 * CPS;                      // LDS reads per pair of gathered fragments
     // the same format on the shapes with a single weight fragment per wave: hand-issued reads, in batches of k-steps
     constexpr bool BATCH = D == 8 && M == 1 && !PIPE && !(ABL & (8 | 16));
     // Blocks walk several tiles where the main loop is scheduled by hand; the compiler-scheduled formats keep one
@@ -379,9 +424,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
     // Operand registers of the hand-pipelined stage.  With one stage per step they live across stages: a stage can
     // request the first operands of the next one (mode bit 1), which then finds them issued (mode bit 0); the
     // register set the gathers rotate through starts at `mode >> 2`.  Never across a branch or the loop's back edge.
-    u32x4 xfr[2][WT], P[3][2];
+    u32x4 xfr[2][WT];
+    GatherFrag<D> P[3][2];
     constexpr int NGK = KT * 2 * (WN / 2);           // groups per stage of the hand-pipelined path
-    constexpr bool XS = PIPE && SPU == 1 && CB == 1 && !(ABL & 1);   // two-byte codes: no registers to spare
+    constexpr bool XS = PIPE && D == 8 && SPU == 1 && CB == 1 && !(ABL & 1);   // two-byte codes: no registers to spare
     auto step = [&](const piece_t (&cur)[PPU][WN], piece_t (&lands)[PPU][WN], piece_t (&req)[PPU][WN], int u, auto own_c,
                     auto mode_c) {
         constexpr bool own = decltype(own_c)::value;
@@ -411,14 +457,18 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                 // (two sets).  LDS reads return in order, so `lgkmcnt(n)` = all but the n newest.
                 constexpr int NKS = KT * 2, NPAIR = WN / 2, NG = NKS * NPAIR;
                 const uint32_t xs0 = xlane[0] + (uint32_t)buf * STAGE_BYTES, xs1 = xlane[1] + (uint32_t)buf * STAGE_BYTES;
-                auto gather_pair = [&](auto gc, u32x4 (&dst)[2]) {        // group gc -> its two weight fragments
+                auto gather_pair = [&](auto gc, GatherFrag<D> (&dst)[2]) {        // group gc -> its two weight fragments
                     constexpr int g = decltype(gc)::value, kk = g / NPAIR, pp = g % NPAIR;
                     constexpr int tt_in = kk / 2, ks = kk % 2;
                     const int tt = sg * KT + tt_in;
                     const int sidx = (tt % TPP) * 2 + ks;
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        dst[e] = lds_read16<0>(gather_addr8<CB>(cur[tt / TPP][2 * pp + e], sidx, (uint32_t)nbits, shift, img_lane));
+                        uint32_t ad[CPS];
+#pragma unroll
+                        for (int cc = 0; cc < CPS; ++cc)
+                            ad[cc] = gather_addr8<CB>(cur[tt / TPP][2 * pp + e], sidx * CPS + cc, (uint32_t)nbits, shift, img_lane);
+                        dst[e].read(ad);
                     }
                 };
                 auto read_x = [&](auto kc) {                               // the WT activation fragments of k-step kk
@@ -441,10 +491,12 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                     constexpr int g = decltype(gc)::value, kk = g / NPAIR, pp = g % NPAIR, c = (g + BASE) % 3, xb = kk & 1;
                     constexpr bool G2 = g + 2 < NG, XR = xr(g) > 0;
                     constexpr int g2 = G2 ? g + 2 : g, kk2 = g2 / NPAIR, pp2 = g2 % NPAIR;
-                    constexpr int newer_all = pipe_newer<NG, NPAIR, NKS, WT, PRE>(g);
+                    constexpr int newer_all = pipe_newer<NG, NPAIR, NKS, WT, PRE, GR>(g);
                     constexpr int newer = newer_all > 15 ? 15 : newer_all;   // the counter has four bits; waiting for more is safe
                     constexpr bool HANDOVER = NEXT && g == NG - 1;     // this group's gaps carry the next stage's first reads
-                    asm volatile("s_waitcnt lgkmcnt(%2)\n\t; PQL %0\n\t; PQL %1" : "+v"(P[c][0]), "+v"(P[c][1]) : "n"(newer));
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(newer));
+                    P[c][0].landed();
+                    P[c][1].landed();
                     if constexpr (pp == 0) {
 #pragma unroll
                         for (int j = 0; j < WT; ++j) asm volatile("; PQL %0" : "+v"(xfr[xb][j]));
@@ -465,19 +517,26 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                     }
                     // the group's 2*WT MFMAs with its LDS traffic spread over the gaps between them, one or two
                     // instructions a gap: both gather addresses, the two gathers, then the next k-step's activations
-                    uint32_t ga[2] = {0u, 0u};
+                    uint32_t ga[2][CPS];
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2)
+#pragma unroll
+                        for (int cc = 0; cc < CPS; ++cc) ga[e2][cc] = 0u;
+                    const u32x4 pa[2] = {P[c][0].value(), P[c][1].value()};
                     static_for<2 * WT>([&](auto mc) {
                         constexpr int m = decltype(mc)::value, j = m / 2, e = m % 2;
-                        acc[2 * pp + e][j] = Act<AT>::mfma16(__builtin_bit_cast(vec8, P[c][e]),
+                        acc[2 * pp + e][j] = Act<AT>::mfma16(__builtin_bit_cast(vec8, pa[e]),
                                                              __builtin_bit_cast(vec8, xfr[xb][j]), acc[2 * pp + e][j]);
                         if constexpr (G2 && m == 0) {
                             const int tt = sg * KT + kk2 / 2;
                             const int sidx = (tt % TPP) * 2 + kk2 % 2;
 #pragma unroll
                             for (int e2 = 0; e2 < 2; ++e2)
-                                ga[e2] = gather_addr8<CB>(cur[tt / TPP][2 * pp2 + e2], sidx, (uint32_t)nbits, shift, img_lane);
+#pragma unroll
+                                for (int cc = 0; cc < CPS; ++cc)
+                                    ga[e2][cc] = gather_addr8<CB>(cur[tt / TPP][2 * pp2 + e2], sidx * CPS + cc, (uint32_t)nbits, shift, img_lane);
                         }
-                        if constexpr (G2 && (m == 1 || m == 2)) P[(g2 + BASE) % 3][m - 1] = lds_read16<0>(ga[m - 1]);
+                        if constexpr (G2 && (m == 1 || m == 2)) P[(g2 + BASE) % 3][m - 1].read(ga[m - 1]);
                         if constexpr (HANDOVER) {
                             // fillers of the hand-over: addresses, gathers of the next stage's groups 0 and 1 (from the
                             // codes that have just landed), its first activation fragments (next ring slot)
@@ -495,7 +554,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                                             na[2 * h + e2] = gather_addr8<CB>(lands[tth / TPP][2 * pph + e2], sidxh, (uint32_t)nbits, shift, img_lane);
                                     }
                                 } else if constexpr (i <= 4) {
-                                    P[((i - 1) / 2 + NB_) % 3][(i - 1) % 2] = lds_read16<0>(na[i - 1]);
+                                    if constexpr (D == 8) {
+                                        const uint32_t one[1] = {na[i - 1]};
+                                        P[((i - 1) / 2 + NB_) % 3][(i - 1) % 2].read(one);
+                                    }
                                 } else {
                                     constexpr int jx = i - 5;
                                     const uint32_t nbuf = buf == NBUF - 1 ? 0u : (uint32_t)buf + 1u;
@@ -808,7 +870,9 @@ template <typename AT, typename CodeT, int D, int M, int WAVES_T, int WN, int WT
 static hipError_t tiled_launch_cfg(const GemmArgs &a, hipStream_t stream) {
     constexpr int BN = (TL_WAVES / WAVES_T) * WN * 16;
     constexpr int BT = WAVES_T * WT * 16;
-    const int R = stream_replication<D>(a.K, a.M);
+    // d = 2 with one-byte codes: 64 copies (a copy per lane; 256 bytes per entry, which the hand-pipelined stage's
+    // gather addresses assume) -- 64 KiB at 256 entries
+    const int R = (D == 2 && sizeof(CodeT) == 1) ? 64 : stream_replication<D>(a.K, a.M);
     const int nbits = __builtin_ctz((unsigned)a.K);
     const int n_tiles = tiles_in(a.parts, BN);
     const int t_tiles = (a.T + BT - 1) / BT;
@@ -865,7 +929,7 @@ static int tiled_step_tiles(const GemmArgs &a, int kt) {
 // or operand registers per k-step, and the 256 x 256 shape would not fit the register file: its slot is a 256 x 128 tile with one
 // k-tile per stage.
 static TiledCfg tiled_cfg(const GemmArgs &a, int i) {
-    if (i == 0 && (a.d == 2 || (a.d == 4 && a.code_bytes == 2) || a.M == 2)) return TiledCfg{256, 128, 1};
+    if (i == 0 && (a.d == 2 || a.d == 4 || a.M == 2)) return TiledCfg{256, 128, 1};
     // the 512 x 128 shape exists for d = 8, one codebook, one-byte codes; other formats run 256 x 128 in its slot
     if (i == 6 && !(a.d == 8 && a.M == 1 && a.code_bytes == 1)) return kTiledCfgs[1];
     return kTiledCfgs[i];
@@ -899,7 +963,7 @@ template <typename AT, typename CodeT, int D, int M>
 static hipError_t tiled_launch_fmt(const GemmArgs &a, hipStream_t stream) {
     switch (choose_tiled_cfg(a)) {
     case 0:
-        if constexpr (D == 2 || (D == 4 && sizeof(CodeT) == 2) || M == 2) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 1>(a, stream);   // 256 x 128
+        if constexpr (D == 2 || D == 4 || M == 2) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 1>(a, stream);   // 256 x 128
         else return tiled_launch_cfg<AT, CodeT, D, M, 4, 8, 4, 1>(a, stream);                    // 256 x 256
     case 1: return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 2>(a, stream);   // 256 x 128
     case 2: return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 4, 2>(a, stream);   // 128 x 128
