@@ -219,10 +219,12 @@ int pq_fused_add_rms_norm(void *x, int64_t x_row_stride, void *residual, int64_t
 /*
  * gate_up_proj with its activation: y[t][n] = silu(g[t][n]) * u[t][n], n < I, where [g | u] = pq_gemm_packed of a
  * layer with the two equal output partitions {I, I} (gate_proj, up_proj; M = 1) -- what LlamaMLP.forward computes
- * with gate_up_proj followed by act_fn (vllm/model_executor/models/llama.py:89-93).  The result is bit-identical
- * to pq_gemm_packed followed by pq_silu_and_mul.  For small batches of the d = 8 / one-byte-code format the
- * activation runs in the epilogue of the streaming kernel (one launch, [T][2 I] never written);
- * pq_gemm_silu_mul_is_fused() says whether it does for a problem.  Otherwise the library runs the two steps
+ * with gate_up_proj followed by act_fn (vllm/model_executor/models/llama.py:89-93).  The result has the roundings
+ * of pq_gemm_packed followed by pq_silu_and_mul and is bit-identical to them wherever both run their sums in the same
+ * order (always when the two steps are run; fused: when pq_gemm_packed takes the same kernel for the layer, as it
+ * does for the layers the decode kernel fuses).  For small batches of the d = 8 / one-byte-code format the
+ * activation runs in the epilogue of the decode kernel or of the streaming kernel (one launch, [T][2 I] never
+ * written); pq_gemm_silu_mul_is_fused() says whether it does for a problem.  Otherwise the library runs the two steps
  * through `tmp`, caller-owned [T][2 I] in the act dtype (it may be NULL when the call is fused).
  * `workspace` as for pq_gemm_packed.  No reference counterpart (the reference always runs two ops).
  */

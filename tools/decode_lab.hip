@@ -53,6 +53,7 @@ static void run(const Shape &sh, int T, int waves_force, int nf_force, bool stam
     p.aux_off = (uint32_t)dc_lds_main_bytes(g.waves, p.img_bytes);
     p.ksplit = g.ksplit; p.cpb = g.cpb; p.n_total = N; p.ws_cnt = (unsigned *)a.workspace;
     p.ws_part = (float *)((unsigned char *)a.workspace + WS_COUNTER_BYTES);
+    p.act_rows = 0; p.phases = 2;
     const int rows = (g.waves >> g.wk_log2) * g.nf * 16;
     p.tmap = make_tile_map(a.parts, rows);
     const int ntile = tiles_in(a.parts, rows), nblk = ntile * g.ksplit;

@@ -425,9 +425,12 @@ int pq_gemm_silu_mul_is_fused(int32_t T, int32_t I, int32_t G, int32_t K, int32_
     return pq::packable(a.parts, G, d, K, 1, code_bytes) && pq::gemm_stream_act_supported(a) ? 1 : 0;
 }
 
-// The decode kernel's fused launch where it takes the problem (at most 16 tokens here: the entry's fused range), else
-// the streaming kernel's.
-static bool decode_act_taken(const pq::GemmArgs &a) { return a.T <= 16 && pq::gemm_decode_act_supported(a); }
+// The decode kernel's fused launch where it takes the problem (at most 16 tokens here: the entry's fused range) and
+// where the decode kernel is the faster one for the unfused layer too (gemm_decode_preferred's rule), else the
+// streaming kernel's.
+static bool decode_act_taken(const pq::GemmArgs &a) {
+    return a.T <= 16 && (a.G / 64 > 2 || a.N > 4096) && pq::gemm_decode_act_supported(a);
+}
 
 int pq_gemm_packed_silu_mul(const void *x, int32_t T, int64_t x_row_stride, const void *packed_codes,
                             const void *codebooks, const void *scales, const void *bias, int32_t I, int32_t G,
