@@ -385,8 +385,8 @@ def layer_chain(stack, T, device, dtype, cfg=LLAMA3_8B, reps=5):
     # apply_normed: decode batches, one rank): o_proj -> [add, norm] -> gate_up_proj, down_proj -> [add, norm] -> the
     # next layer's qkv_proj; the first layer's input norm and the activation stay launches of their own.
     qm = stack[0]["o_proj"].quant_method
-    fusable = all(qm.norm_pair_supported(b["o_proj"], b["gate_up_proj"], T) and
-                  qm.norm_pair_supported(b["down_proj"], b["qkv_proj"], T) for b in stack[:1])
+    fusable = all(qm.norm_pair_preferred(b["o_proj"], b["gate_up_proj"], T) and
+                  qm.norm_pair_preferred(b["down_proj"], b["qkv_proj"], T) for b in stack[:1])
 
     def step_fused():
         h, res = x0.clone(), x0.clone()

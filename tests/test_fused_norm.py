@@ -120,6 +120,23 @@ def test_norm_pair_supported_through_the_method():
     big = make(RowParallelLinear, 512, 8192)
     gu8 = make(MergedColumnParallelLinear, 8192, [64, 64])
     assert not m.norm_pair_supported(big, gu8, 16)
+    # preferred: whenever supported up to 48 tokens; beyond, only where the plain dispatch runs both layers on the
+    # decode kernel anyway
+    assert m.norm_pair_preferred(o, gu, 16) and m.norm_pair_preferred(o, gu, 48)
+    assert not m.norm_pair_preferred(o, gu, 129)
+    from vllm_pq_amd import ops
+
+    def plain(layer, t):
+        n, g, _ = layer.codes.shape
+        parts = list(layer.codebooks.output_partition_sizes)
+        return ops.gemm_kernel_name(t, n, g, 1, 256, 8, 1, torch.bfloat16, parts, packed=True)
+    for t in (64, 128):
+        both = plain(o, t) == "mfma_decode_packed" and plain(gu, t) == "mfma_decode_packed"
+        assert m.norm_pair_preferred(o, gu, t) == both
+    o8 = make(RowParallelLinear, 4096, 4096)
+    gu8 = make(MergedColumnParallelLinear, 4096, [14336, 14336])
+    assert m.norm_pair_supported(o8, gu8, 128) and not m.norm_pair_preferred(o8, gu8, 128)
+    assert m.norm_pair_preferred(o8, gu8, 32)
     res = torch.randn(5, 1024, device=DEV).to(torch.bfloat16)
     w = torch.ones(1024, device=DEV, dtype=torch.bfloat16)
     x = torch.randn(5, 1024, device=DEV).to(torch.bfloat16)

@@ -247,6 +247,26 @@ class PQLinearMethod(LinearMethodBase):
                 and ops.gemm_add_norm_supported(tokens, first.codes, first.codebooks, pf)
                 and ops.gemm_normed_supported(tokens, second.codes, second.codebooks, ps))
 
+    def norm_pair_preferred(self, first: torch.nn.Module, second: torch.nn.Module, tokens: int) -> bool:
+        """norm_pair_supported, and the pair is not slower than the three separate steps: both GEMMs of the pair run
+        on the decode kernel, which takes more than 16 tokens as groups of 16 that each gather the weights again.  Up
+        to 48 tokens the two norm launches saved outweigh that on every layer size measured (32 Llama-3-8B layers:
+        1.54 against 1.65 ms at 32 tokens, level at 48, 2.53 against 2.26 ms at 64); beyond, only where the plain
+        dispatch picks the decode kernel for both layers anyway (layers whose blocks hold few units)."""
+        if not self.norm_pair_supported(first, second, tokens):
+            return False
+        if tokens <= 48:
+            return True
+        for layer in (first, second):
+            N, G, M = layer.codes.shape
+            cb = layer.codebooks
+            parts = list(getattr(cb, "output_partition_sizes", [])) or [N]
+            name = ops.gemm_kernel_name(tokens, N, G, M, cb.shape[1], cb.shape[3], layer.codes.element_size(),
+                                        cb.dtype, parts, packed=True)
+            if name != "mfma_decode_packed":
+                return False
+        return True
+
     def apply_add_norm(self, layer: torch.nn.Module, x: torch.Tensor, residual: torch.Tensor,
                        norm_weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
         """apply() of the linear in front of `RMSNorm.forward(x, residual)` (vllm/model_executor/layers/layernorm.py:
