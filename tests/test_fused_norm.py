@@ -204,3 +204,46 @@ def test_normed_gate_up_with_activation_limits():
         want = torch.empty(5, 256, dtype=torch.bfloat16, device=DEV)
         ops.silu_and_mul(want, y)
         assert torch.equal(m.apply_normed_silu_and_mul(layer, xw, ssq, EPS).view(torch.int16), want.view(torch.int16))
+
+
+def _random_act_cases(n=24, seed=77):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        H = int(rng.choice([512, 1024, 1536, 2048, 2560, 3072, 3584, 4096]))
+        I = 16 * int(rng.integers(1, 130))
+        T = int(rng.choice([1, 2, 3, 5, 8, 9, 15, 16, 17, 31, 33, 64, 100, 128]))
+        out.append((i, T, H, I, bool(rng.integers(0, 2)), "bf16" if rng.integers(0, 2) else "fp16"))
+    return out
+
+
+@pytest.mark.parametrize("i,T,H,I,bias,dtype", _random_act_cases(), ids=lambda v: str(v))
+def test_normed_gate_up_with_activation_random_shapes(i, T, H, I, bias, dtype):
+    """Seeded random layer sizes (ragged row tiles, every chunk count up to 8), token counts across the token
+    groups, both dtypes: the fused launch against the two steps, bit for bit; and the plain fused entry at up to 16
+    tokens against the same two steps without the norm (within the layers' tolerance where the unfused GEMM runs on
+    another kernel)."""
+    from vllm_pq_amd import ops
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    p = _layer(7000 + i, [I, I], H, dtype, bias)
+    pk = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, [I, I])
+    g = torch.Generator(device="cpu").manual_seed(7100 + i)
+    xw = (torch.randn(T, H, generator=g) * 0.25).to(tdt).to(DEV)
+    ssq = (torch.rand(H // 16, (T + 15) // 16 * 16, generator=g) * 16 + 4).to(DEV)
+    ops.ensure_workspace(torch.device(DEV))
+    assert ops.gemm_normed_silu_mul_supported(T, p.codes_dev, p.codebooks_dev)
+    y = ops.pq_gemm_packed_normed(xw, ssq, EPS, pk, p.codes_dev, p.codebooks_dev, p.scales_dev, [I, I], p.bias_dev)
+    want = torch.empty(T, I, dtype=tdt, device=DEV)
+    ops.silu_and_mul(want, y)
+    got = ops.pq_gemm_packed_normed_silu_mul(xw, ssq, EPS, pk, p.codes_dev, p.codebooks_dev, p.scales_dev, p.bias_dev)
+    gb, wb = got.view(torch.int16), want.view(torch.int16)
+    assert torch.equal(gb, wb), f"{int((gb != wb).sum())} of {got.numel()} values differ"
+    if T <= 16:
+        y2 = ops.pq_gemm_packed(xw, pk, p.codes_dev, p.codebooks_dev, p.scales_dev, [I, I], p.bias_dev)
+        want2 = torch.empty(T, I, dtype=tdt, device=DEV)
+        ops.silu_and_mul(want2, y2)
+        got2 = ops.pq_gemm_packed_silu_mul(xw, pk, p.codes_dev, p.codebooks_dev, p.scales_dev, p.bias_dev)
+        ok = torch.isfinite(want2.float()) & torch.isfinite(got2.float())
+        err = (got2.float() - want2.float()).abs()[ok]
+        lim = (2.0 ** -6 if dtype == "bf16" else 2.0 ** -9) * want2.float().abs()[ok] + 1e-3
+        assert (err <= lim).all(), f"{int((err > lim).sum())} values beyond two ulp"
