@@ -640,6 +640,12 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 });
             } else {
+            // the lane's row and k-quad from an opaque copy of the lane number: the activation addresses derived from
+            // them are then worked out per stage (a few instructions) instead of staying in registers across the
+            // whole main loop for the code behind it
+            int lane_s = lane;
+            asm volatile("" : "+v"(lane_s));
+            const int r16 = lane_s & 15, q = lane_s >> 4;
 #pragma unroll
             for (int it = 0; it < KT; ++it) {
                 const int tt = sg * KT + it;           // tile within the loop step (compile-time)
@@ -925,11 +931,14 @@ static int tiled_step_tiles(const GemmArgs &a, int kt) {
     return kt > tpp ? kt : tpp;
 }
 
-// Shape i for this format.  With d = 2 (and d = 4 with two-byte codes, and two codebooks) a lane holds more code
-// or operand registers per k-step, and the 256 x 256 shape would not fit the register file: its slot is a 256 x 128 tile with one
-// k-tile per stage.
+// Shape i for this format.  With d = 2 and d = 4 a lane holds more code or operand registers per k-step, and the
+// 256 x 256 shape would not fit the register file: its slot is a 256 x 128 tile with one k-tile per stage.  With two
+// codebooks the slot is a 256 x 256 tile whose waves take 4 weight fragments x 8 token fragments (instead of 8 x 4),
+// and the 128 x 128 shape's slot a 128 x 256 tile of 2 x 8 fragments a wave.
 static TiledCfg tiled_cfg(const GemmArgs &a, int i) {
-    if (i == 0 && (a.d == 2 || a.d == 4 || a.M == 2)) return TiledCfg{256, 128, 1};
+    if (i == 0 && a.M == 2) return TiledCfg{256, 256, 1};
+    if (i == 2 && a.M == 2) return TiledCfg{128, 256, 1};
+    if (i == 0 && (a.d == 2 || a.d == 4)) return TiledCfg{256, 128, 1};
     // the 512 x 128 shape exists for d = 8, one codebook, one-byte codes; other formats run 256 x 128 in its slot
     if (i == 6 && !(a.d == 8 && a.M == 1 && a.code_bytes == 1)) return kTiledCfgs[1];
     return kTiledCfgs[i];
@@ -944,7 +953,12 @@ static int choose_tiled_cfg(const GemmArgs &a) {
     // block costs its tile area over the shape's measured throughput (PFLOP/s on a chip-filling problem:
     // bigger tiles reuse each gathered weight fragment and each activation fragment more often).  Padding
     // and half-filled last rounds are paid in full; ties go to the larger tile.
-    static const double speed[kNumTiledCfgs] = {1.33, 1.29, 1.085, 1.13, 0.856, 0.622, 1.355};
+    static const double speed_one[kNumTiledCfgs] = {1.33, 1.29, 1.085, 1.13, 0.856, 0.622, 1.355};
+    // two codebooks: every weight fragment is two gathers and eight rounded sums, so what counts is how many MFMAs a
+    // fragment feeds -- 8 in the slots of the 256 x 256 and 128 x 128 shapes (256 x 256 and 128 x 256 tiles whose
+    // waves take 8 token fragments), 4 or 2 elsewhere
+    static const double speed_two[kNumTiledCfgs] = {0.92, 0.59, 0.87, 0.55, 0.50, 0.31, 0.59};
+    const double *speed = a.M == 2 ? speed_two : speed_one;
     static const int order[kNumTiledCfgs] = {6, 0, 1, 2, 3, 4, 5};
     int best = 0;   // shape 0 takes any Kin the kernel supports
     double best_cost = -1.0;
@@ -952,7 +966,8 @@ static int choose_tiled_cfg(const GemmArgs &a) {
         const TiledCfg c = tiled_cfg(a, i);
         if ((a.G * a.d) % (64 * tiled_step_tiles(a, c.kt))) continue;
         const long blocks = (long)tiles_in(a.parts, c.bn) * ((a.T + c.bt - 1) / c.bt);
-        const double sp = (c.bn == kTiledCfgs[i].bn && c.bt == kTiledCfgs[i].bt) ? speed[i] : speed[1];
+        // (the two-codebook table is per slot; a one-codebook format whose slot holds another shape runs 256 x 128 there)
+        const double sp = (a.M == 2 || (c.bn == kTiledCfgs[i].bn && c.bt == kTiledCfgs[i].bt)) ? speed[i] : speed[1];
         const double cost = (double)((blocks + 255) / 256) * c.bn * c.bt / sp;
         if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = i; }
     }
@@ -963,10 +978,13 @@ template <typename AT, typename CodeT, int D, int M>
 static hipError_t tiled_launch_fmt(const GemmArgs &a, hipStream_t stream) {
     switch (choose_tiled_cfg(a)) {
     case 0:
-        if constexpr (D == 2 || D == 4 || M == 2) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 1>(a, stream);   // 256 x 128
+        if constexpr (M == 2) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 8, 1>(a, stream);   // 256 x 256, 8 token fragments a wave: every summed weight fragment feeds 8 MFMAs
+        else if constexpr (D == 2 || D == 4) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 1>(a, stream);   // 256 x 128
         else return tiled_launch_cfg<AT, CodeT, D, M, 4, 8, 4, 1>(a, stream);                    // 256 x 256
     case 1: return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 2>(a, stream);   // 256 x 128
-    case 2: return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 4, 2>(a, stream);   // 128 x 128
+    case 2:
+        if constexpr (M == 2) return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 8, 1>(a, stream);   // 128 x 256, 8 token fragments a wave
+        else return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 4, 2>(a, stream);   // 128 x 128
     case 3: return tiled_launch_cfg<AT, CodeT, D, M, 1, 2, 4, 4>(a, stream);   // 256 x 64
     case 4: return tiled_launch_cfg<AT, CodeT, D, M, 1, 1, 4, 4>(a, stream);   // 128 x 64
     case 6:
