@@ -123,6 +123,13 @@ def enable_launch_log(stack, dtype):
         record(input, codes, codebooks, [codes.shape[0] // 2] * 2, True, fused="+silu_mul")
         return fused(input, packed_codes, codes, codebooks, scales, bias)
 
+    prepared = ops.pq_gemm_packed_prepared
+
+    def gemm_packed_prepared(desc, input, bias=None):
+        record(input, desc.codes, desc.codebooks, [desc.parts[i] for i in range(desc.nparts)], True)
+        return prepared(desc, input, bias)
+
+    ops.pq_gemm_packed_prepared = gemm_packed_prepared
     add_norm, normed = ops.pq_gemm_packed_add_norm, ops.pq_gemm_packed_normed
 
     def gemm_packed_add_norm(input, packed_codes, codes, codebooks, scales, codebook_partition_sizes, bias, residual,

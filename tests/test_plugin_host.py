@@ -215,3 +215,25 @@ def test_custom_ops_trace_with_fake_tensors():
         assert torch.ops.pq_amd.silu_and_mul(out, x) is None
         assert torch.ops.pq_amd.fused_add_rms_norm(x, torch.empty_like(x), torch.empty(64, dtype=torch.bfloat16,
                                                                                        device="cuda"), 1e-6) is None
+
+
+def test_public_wrappers_route_fake_tensors_through_the_ops():
+    """Plain eager CUDA tensors go straight to the implementation (no per-call dispatcher cost); anything else --
+    fake tensors here -- takes the registered op and its fake implementation."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from vllm_pq_amd import ops
+    if not ops._HAVE_CUSTOM_OP:
+        pytest.skip("this torch has no torch.library.custom_op")
+    assert not ops._via_op(torch.empty(2, 2), None)          # a plain tensor: direct
+    with FakeTensorMode():
+        x = torch.empty(7, 64, dtype=torch.bfloat16, device="cuda")
+        codes = torch.empty(96, 8, 1, dtype=torch.int8, device="cuda")
+        cb = torch.empty(2, 256, 1, 8, dtype=torch.bfloat16, device="cuda")
+        sc = torch.empty(96, 1, 1, 1, dtype=torch.bfloat16, device="cuda")
+        assert ops._via_op(x, codes)
+        assert ops.pq_gemm(x, codes, cb, sc, [64, 32], None).shape == (7, 96)
+        packed = torch.empty(96 // 16 * 1024, dtype=torch.uint8, device="cuda")
+        assert ops.pq_gemm_packed(x, packed, codes, cb, sc, [64, 32], None).shape == (7, 96)
+        assert ops.pq_dequant(codes, cb, [64, 32]).shape == (96, 64)
+        out = torch.empty(7, 32, dtype=torch.bfloat16, device="cuda")
+        assert ops.silu_and_mul(out, x) is None

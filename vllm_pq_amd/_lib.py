@@ -141,6 +141,13 @@ def last_error() -> str:
     return load().pq_last_error().decode("utf-8", "replace")
 
 
+_PARTS_ARRAYS = {}
+
+
 def parts_array(sizes):
-    arr = (ctypes.c_int32 * len(sizes))(*[int(s) for s in sizes])
+    """ctypes int32 array of the partition sizes (read-only for the library: one shared array per distinct list)."""
+    key = tuple(sizes)
+    arr = _PARTS_ARRAYS.get(key)
+    if arr is None:
+        arr = _PARTS_ARRAYS[key] = (ctypes.c_int32 * len(key))(*[int(s) for s in key])
     return arr

@@ -21,8 +21,33 @@ _DTYPE = {torch.float16: _lib.PQ_DTYPE_FP16, torch.bfloat16: _lib.PQ_DTYPE_BF16}
 _CODE_BYTES = {torch.int8: 1, torch.int16: 2}
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr(device) -> int:
+    """The current stream of `device` as the integer the C ABI takes (a call is on the host path of every launch:
+    the raw query is several times cheaper than building a torch.cuda.Stream object)."""
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _on_device:
+    """`with _on_device(dev):` -- torch.cuda.device(dev), entered only when dev is not the current device already."""
+    __slots__ = ("guard",)
+
+    def __init__(self, dev):
+        self.guard = None if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            return self.guard.__exit__(*exc)
+        return False
 
 
 def _check_device(*tensors):
@@ -93,7 +118,7 @@ def ensure_workspace(device: torch.device, nbytes: Optional[int] = None) -> None
         return
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
-    for key in ((idx, torch.cuda.current_stream(idx).cuda_stream), (idx, "graph")):
+    for key in ((idx, _stream_ptr(torch.device("cuda", idx))), (idx, "graph")):
         if key not in _WORKSPACE:
             _WORKSPACE[key] = _new_workspace(idx)
 
@@ -107,7 +132,7 @@ def _workspace(dev: torch.device) -> Optional[torch.Tensor]:
         return _WORKSPACE.get((idx, "graph"))
     if (idx, "graph") not in _WORKSPACE:      # the device never asked for workspaces (or dropped them)
         return None
-    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    key = (idx, _stream_ptr(dev))
     ws = _WORKSPACE.get(key)
     if ws is None:
         ws = _WORKSPACE[key] = _new_workspace(idx)
@@ -138,7 +163,7 @@ def _pq_dequant_impl(codes: torch.Tensor, codebooks: torch.Tensor, codebook_part
             raise ValueError("scales must hold one value of the codebooks' dtype per output row")
         scales = scales.contiguous()
     out = torch.empty((N, G * d), dtype=codebooks.dtype, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = L.pq_dequant(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr() if scales is not None else None,
                           _lib.parts_array(parts), len(parts), N, G, M, K, d, _CODE_BYTES[codes.dtype],
                           _DTYPE[codebooks.dtype], out.data_ptr(), _stream_ptr(dev))
@@ -162,7 +187,7 @@ def _pq_embedding_impl(input_ids: torch.Tensor, codes: torch.Tensor, codebooks: 
     T = ids.numel()
     out = torch.empty((T, G * d), dtype=codebooks.dtype, device=dev)
     if T and G:
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = L.pq_embedding(ids.data_ptr(), T, codes.contiguous().data_ptr(), codebooks.contiguous().data_ptr(),
                                 scales.data_ptr() if scales is not None else None, _lib.parts_array(parts), len(parts),
                                 N, G, M, K, d, _CODE_BYTES[codes.dtype], _DTYPE[codebooks.dtype], out.data_ptr(), G * d,
@@ -198,7 +223,7 @@ def _pq_gemm_impl(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Ten
         bias = bias.contiguous()
     out = torch.empty((T, N), dtype=input.dtype, device=dev)
     if T and N:
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             ws = _workspace(dev)
             fn = L.pq_gemm if packed_codes is None else L.pq_gemm_packed
             cptr = codes.data_ptr() if packed_codes is None else packed_codes.data_ptr()
@@ -209,11 +234,87 @@ def _pq_gemm_impl(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Ten
                            ws.numel() if ws is not None else 0, _stream_ptr(dev))
         if rc:
             _raise(rc)
-    return out.reshape(input.shape[:-1] + (N,))
+    return out if input.dim() == 2 else out.reshape(input.shape[:-1] + (N,))
+
+
+class PackedLinear:
+    """A loaded layer's launch arguments, validated once (pq_gemm_packed checks shapes, dtypes and devices of five
+    weight tensors on every call: several microseconds of host time, as long as a decode launch runs).  Holds the
+    tensors it points into; `matches()` tells whether they are still the ones the layer holds."""
+    __slots__ = ("packed", "codes", "codebooks", "scales", "ptrs", "N", "G", "M", "K", "d", "cb", "dtype", "tdtype",
+                 "parts", "nparts", "device", "features")
+
+    def __init__(self, packed_codes: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor,
+                 codebook_partition_sizes: List[int]):
+        dev = _check_device(packed_codes, codes, codebooks, scales)
+        N, G, M, K, d, parts = _format(codes, codebooks, codebook_partition_sizes)
+        if scales.numel() != N or scales.dtype != codebooks.dtype:
+            raise ValueError("scales must hold one value of the activation dtype per output row")
+        if not (codebooks.is_contiguous() and scales.is_contiguous() and packed_codes.is_contiguous()):
+            raise ValueError("contiguous weight tensors expected")
+        self.packed, self.codes, self.codebooks, self.scales = packed_codes, codes, codebooks, scales
+        self.ptrs = (packed_codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr())
+        self.N, self.G, self.M, self.K, self.d = N, G, M, K, d
+        self.cb, self.dtype, self.tdtype = _CODE_BYTES[codes.dtype], _DTYPE[codebooks.dtype], codebooks.dtype
+        self.parts, self.nparts = _lib.parts_array(parts), len(parts)
+        self.device, self.features = dev, G * d
+
+    def matches(self, packed_codes: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor) -> bool:
+        return self.ptrs == (packed_codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr())
+
+
+def pq_gemm_packed_prepared(desc: PackedLinear, input: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pq_gemm_packed for a layer prepared with PackedLinear: the same launch, the per-call checks reduced to the
+    activations and the bias.  Under torch.compile and for fake tensors it goes through the registered op."""
+    if _via_op(input, bias):
+        return torch.ops.pq_amd.gemm_packed(input, desc.packed, desc.codes, desc.codebooks, desc.scales,
+                                            [desc.parts[i] for i in range(desc.nparts)], bias)
+    dev, N = desc.device, desc.N
+    if input.device != dev or input.dtype != desc.tdtype or input.shape[-1] != desc.features:
+        if not input.is_cuda:
+            raise RuntimeError(
+                f"vllm_pq_amd ops run on MI355X only: got a tensor on '{input.device}'. There is no CPU fallback.")
+        raise ValueError(f"input {tuple(input.shape)} {input.dtype} on {input.device} does not match the weight "
+                         f"({desc.features} features, {desc.tdtype}, {dev})")
+    bptr = None
+    if bias is not None:
+        if bias.device != dev or bias.numel() != N or bias.dtype != desc.tdtype:
+            raise ValueError("bias must hold one value of the activation dtype per output row, on the weight's device")
+        bptr = bias.contiguous().data_ptr()
+    x2 = input if input.dim() == 2 else input.reshape(-1, desc.features)
+    if x2.stride(-1) != 1 or x2.data_ptr() % 16 or x2.stride(0) % 8:
+        x2 = x2.contiguous()
+    T = x2.shape[0]
+    out = torch.empty((T, N), dtype=desc.tdtype, device=dev)
+    if T and N:
+        with _on_device(dev):
+            ws = _workspace(dev)
+            rc = _lib.load().pq_gemm_packed(
+                x2.data_ptr(), T, x2.stride(0) if T > 1 else desc.features, desc.ptrs[0], desc.ptrs[1], desc.ptrs[2], bptr,
+                desc.parts, desc.nparts, N, desc.G, desc.M, desc.K, desc.d, desc.cb, desc.dtype, out.data_ptr(), N,
+                ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream_ptr(dev))
+        if rc:
+            _raise(rc)
+    return out if input.dim() == 2 else out.reshape(input.shape[:-1] + (N,))
 
 
 # ---- torch custom ops (schema + fake impl), as the reference registers its ops ----------------
 _HAVE_CUSTOM_OP = hasattr(torch, "library") and hasattr(torch.library, "custom_op")
+_is_compiling = getattr(getattr(torch, "compiler", None), "is_compiling", None)
+
+
+def _via_op(*tensors) -> bool:
+    """Whether a call goes through its registered torch op: under torch.compile / tracing, and for anything that is
+    not a plain CUDA tensor (fake and functional tensors).  Plain eager calls go straight to the implementation: the
+    Python-level dispatch of a custom op costs about 7 us per call, more than a decode launch runs."""
+    if not _HAVE_CUSTOM_OP:
+        return False
+    if _is_compiling is not None and _is_compiling():
+        return True
+    for t in tensors:
+        if t is not None and (type(t) is not torch.Tensor and type(t) is not torch.nn.Parameter):
+            return t.is_cuda
+    return False
 
 if _HAVE_CUSTOM_OP:
 
@@ -261,7 +362,7 @@ def pq_embedding(input_ids: torch.Tensor, codes: torch.Tensor, codebooks: torch.
     """Rows `input_ids` of the dequantised weight, [..., in_features]: F.embedding(input_ids, pq_dequant(...)) bit
     for bit without building the table (UnquantizedEmbeddingMethod.embedding,
     vllm/model_executor/layers/vocab_parallel_embedding.py:45-47, for a PQ-compressed table)."""
-    if _HAVE_CUSTOM_OP and input_ids.is_cuda:
+    if _via_op(input_ids, codes):
         return torch.ops.pq_amd.embedding(input_ids, codes, codebooks, scales, list(codebook_partition_sizes))
     return _pq_embedding_impl(input_ids, codes, codebooks, scales, codebook_partition_sizes)
 
@@ -270,7 +371,7 @@ def pq_gemm(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor, s
             codebook_partition_sizes: List[int], bias: Optional[torch.Tensor]) -> torch.Tensor:
     """y = input @ W^T (+ bias): W is decoded on the fly from codes/codebooks/scales.
     Same signature as ops.aqlm_gemm (vllm/_custom_ops.py:646-652)."""
-    if _HAVE_CUSTOM_OP and input.is_cuda:
+    if _via_op(input, codes):
         return torch.ops.pq_amd.gemm(input, codes, codebooks, scales, list(codebook_partition_sizes), bias)
     return _pq_gemm_impl(input, codes, codebooks, scales, codebook_partition_sizes, bias)
 
@@ -280,7 +381,7 @@ def pq_gemm_packed(input: torch.Tensor, packed_codes: torch.Tensor, codes: torch
                    bias: Optional[torch.Tensor]) -> torch.Tensor:
     """pq_gemm reading the codes from `packed_codes` (pq_repack_codes); `codes` only supplies the
     shape and dtype of the reference-layout tensor."""
-    if _HAVE_CUSTOM_OP and input.is_cuda:
+    if _via_op(input, packed_codes):
         return torch.ops.pq_amd.gemm_packed(input, packed_codes, codes, codebooks, scales,
                                             list(codebook_partition_sizes), bias)
     return _pq_gemm_impl(input, codes, codebooks, scales, codebook_partition_sizes, bias, packed_codes)
@@ -300,7 +401,7 @@ def pq_repack_codes(codes: torch.Tensor, codebooks: torch.Tensor,
         return None
     codes = codes.contiguous()
     packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = L.pq_repack_codes(codes.data_ptr(), pa, len(parts), N, G, M, K, d, _CODE_BYTES[codes.dtype],
                                packed.data_ptr(), _stream_ptr(dev))
     if rc:
@@ -313,7 +414,7 @@ def pq_dequant(codes: torch.Tensor, codebooks: torch.Tensor, codebook_partition_
     """Dense [out_features, in_features] weight.  With scales=None: same signature and result as
     ops.aqlm_dequant (vllm/_custom_ops.py:655-658); with scales it is dequantize_weight per partition
     (aqlm.py:37-74)."""
-    if _HAVE_CUSTOM_OP and codes.is_cuda:
+    if _via_op(codes, codebooks):
         return torch.ops.pq_amd.dequant(codes, codebooks, list(codebook_partition_sizes), scales)
     return _pq_dequant_impl(codes, codebooks, codebook_partition_sizes, scales)
 
@@ -344,7 +445,7 @@ def _pq_gemm_packed_silu_mul_impl(input: torch.Tensor, packed_codes: torch.Tenso
         cb = _CODE_BYTES[codes.dtype]
         fused = L.pq_gemm_silu_mul_is_fused(T, I, G, K, d, cb, _DTYPE[input.dtype])
         tmp = None if fused else torch.empty((T, N), dtype=input.dtype, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             ws = _workspace(dev)
             rc = L.pq_gemm_packed_silu_mul(
                 x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, packed_codes.data_ptr(),
@@ -375,7 +476,7 @@ def pq_gemm_packed_silu_mul(input: torch.Tensor, packed_codes: torch.Tensor, cod
                             bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """silu(g) * u with [g | u] = pq_gemm_packed(input, ...) of a gate/up layer (two equal output partitions):
     bit-identical to pq_gemm_packed followed by silu_and_mul, in one launch for small batches."""
-    if _HAVE_CUSTOM_OP and input.is_cuda:
+    if _via_op(input, packed_codes):
         return torch.ops.pq_amd.gemm_packed_silu_mul(input, packed_codes, codes, codebooks, scales, bias)
     return _pq_gemm_packed_silu_mul_impl(input, packed_codes, codes, codebooks, scales, bias)
 
@@ -427,7 +528,7 @@ def pq_gemm_packed_add_norm(input: torch.Tensor, packed_codes: torch.Tensor, cod
     xw = torch.empty((T, N), dtype=input.dtype, device=dev)
     ssq = torch.empty((N // 16, (T + 15) // 16 * 16), dtype=torch.float32, device=dev)
     if T and N:
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             ws = _workspace(dev)
             rc = L.pq_gemm_packed_add_norm(
                 x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, packed_codes.data_ptr(), codebooks.contiguous().data_ptr(),
@@ -455,7 +556,7 @@ def pq_gemm_packed_normed(xw: torch.Tensor, ssq: torch.Tensor, eps: float, packe
         raise ValueError("xw of the weight's dtype and ssq [in_features / 16, tokens rounded up to 16] fp32 expected")
     out = torch.empty((T, N), dtype=xw.dtype, device=dev)
     if T and N:
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             ws = _workspace(dev)
             rc = L.pq_gemm_packed_normed(
                 x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, packed_codes.data_ptr(), codebooks.contiguous().data_ptr(),
@@ -495,7 +596,7 @@ def pq_gemm_packed_normed_silu_mul(xw: torch.Tensor, ssq: torch.Tensor, eps: flo
         raise ValueError("scales (and bias) must hold one value of the activation dtype per output row")
     out = torch.empty((T, I), dtype=xw.dtype, device=dev)
     if T and I:
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = L.pq_gemm_packed_normed_silu_mul(
                 x2.data_ptr(), T, x2.stride(0) if T > 1 else G * d, packed_codes.data_ptr(), codebooks.contiguous().data_ptr(),
                 scales.contiguous().data_ptr(), bias.contiguous().data_ptr() if bias is not None else None, I, G, K, d, cb,
@@ -529,7 +630,7 @@ def _silu_and_mul_impl(out: torch.Tensor, input: torch.Tensor) -> None:
         raise ValueError(f"silu_and_mul: input {tuple(input.shape)} does not halve into out {tuple(out.shape)}")
     x2, xs = _rows(input, "silu_and_mul input")
     o2, os_ = _rows(out, "silu_and_mul out")
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = L.pq_silu_and_mul(x2.data_ptr(), max(xs, 2 * I), x2.shape[0], I, _DTYPE[input.dtype], o2.data_ptr(),
                                max(os_, I), _stream_ptr(dev))
     if rc:
@@ -546,7 +647,7 @@ def _rms_norm_impl(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor,
         raise ValueError(f"rms_norm: shapes {tuple(input.shape)} -> {tuple(out.shape)}, weight {tuple(weight.shape)}")
     x2, xs = _rows(input, "rms_norm input")
     o2, os_ = _rows(out, "rms_norm out")
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = L.pq_rms_norm(x2.data_ptr(), xs, weight.contiguous().data_ptr(), float(epsilon), x2.shape[0], H,
                            _DTYPE[input.dtype], o2.data_ptr(), os_, _stream_ptr(dev))
     if rc:
@@ -565,7 +666,7 @@ def _fused_add_rms_norm_impl(input: torch.Tensor, residual: torch.Tensor, weight
                          f"weight {tuple(weight.shape)}")
     x2, xs = _rows(input, "fused_add_rms_norm input")
     r2, rs = _rows(residual, "fused_add_rms_norm residual")
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = L.pq_fused_add_rms_norm(x2.data_ptr(), xs, r2.data_ptr(), rs, weight.contiguous().data_ptr(),
                                      float(epsilon), x2.shape[0], H, _DTYPE[input.dtype], _stream_ptr(dev))
     if rc:
@@ -590,21 +691,21 @@ if _HAVE_CUSTOM_OP:
 
 def silu_and_mul(out: torch.Tensor, input: torch.Tensor) -> None:
     """out[..., j] = silu(input[..., j]) * input[..., I + j]; `out` is written in place."""
-    if _HAVE_CUSTOM_OP and input.is_cuda and out.is_cuda:
+    if _via_op(input, out):
         return torch.ops.pq_amd.silu_and_mul(out, input)
     _silu_and_mul_impl(out, input)
 
 
 def rms_norm(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor, epsilon: float) -> None:
     """out = RMS-normalised input times weight (vllm/_custom_ops.py:151-153)."""
-    if _HAVE_CUSTOM_OP and input.is_cuda and out.is_cuda:
+    if _via_op(input, out):
         return torch.ops.pq_amd.rms_norm(out, input, weight, float(epsilon))
     _rms_norm_impl(out, input, weight, epsilon)
 
 
 def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, epsilon: float) -> None:
     """residual += input; input = RMS-norm(residual) * weight, both in place (vllm/_custom_ops.py:156-158)."""
-    if _HAVE_CUSTOM_OP and input.is_cuda and residual.is_cuda:
+    if _via_op(input, residual):
         return torch.ops.pq_amd.fused_add_rms_norm(input, residual, weight, float(epsilon))
     _fused_add_rms_norm_impl(input, residual, weight, epsilon)
 

@@ -174,6 +174,7 @@ class PQLinearMethod(LinearMethodBase):
         # layout, which the checkpoint loaders and pq_dequant use).  On a CPU-resident layer (weights
         # not moved to the GPU yet) there is nothing to do: apply() needs the GPU anyway.
         layer.pq_packed_codes = None
+        layer.pq_prepared = None
         layer.pq_dequant_route = False
         if layer.codes.is_cuda:
             parts = getattr(layer.codebooks, "output_partition_sizes", [])
@@ -204,7 +205,11 @@ class PQLinearMethod(LinearMethodBase):
         parts = getattr(codebooks, "output_partition_sizes", [])
         packed = getattr(layer, "pq_packed_codes", None)
         if packed is not None:
-            return ops.pq_gemm_packed(x, packed, layer.codes, codebooks, layer.scales, parts, bias)
+            # the layer's launch arguments, validated once and again whenever a weight tensor has been replaced
+            desc = getattr(layer, "pq_prepared", None)
+            if desc is None or not desc.matches(packed, codebooks.data, layer.scales.data):
+                desc = layer.pq_prepared = ops.PackedLinear(packed, layer.codes.data, codebooks.data, layer.scales.data, parts)
+            return ops.pq_gemm_packed_prepared(desc, x, bias)
         if getattr(layer, "pq_dequant_route", False) and x.numel() // x.shape[-1] > GENERIC_KERNEL_MAX_TOKENS:
             # the reference's order for this route (aqlm.py:143-156): without bias the GEMM output is scaled,
             # with bias the weight is scaled first
