@@ -269,6 +269,44 @@ def test_apply_through_parallel_linear_layers(ops):
         assert_close_to_exact(bits_of(y), y32, "bf16", type(layer).__name__)
 
 
+def test_apply_follows_replaced_weight_tensors(ops):
+    """apply() keeps a layer's launch arguments validated once; they are rebuilt when a weight tensor is replaced
+    (another storage), never used stale: doubled scales double the output exactly, new codebooks and re-processed
+    codes give the other weight's result, and a wrong input is still refused."""
+    from vllm_pq_amd import PQConfig
+    from vllm_pq_amd.host.linear import RowParallelLinear
+    a = Problem(31, 256, 8, 1, [256], 512, 6, "bf16", bias=False).to(DEV)
+    b = Problem(32, 256, 8, 1, [256], 512, 6, "bf16", bias=False).to(DEV)
+    layer = RowParallelLinear(512, 256, bias=False, params_dtype=torch.bfloat16, quant_config=PQConfig(8, 8, 1, 1))
+    layer.codes.data, layer.codebooks.data, layer.scales.data = a.codes, a.codebooks, a.scales
+    layer.to(DEV)
+    m = layer.quant_method
+    m.process_weights_after_loading(layer)
+    y0 = m.apply(layer, a.x_dev)
+    assert layer.pq_prepared is not None and torch.equal(y0, m.apply(layer, a.x_dev))
+    want = ops.pq_gemm_packed(a.x_dev, layer.pq_packed_codes, layer.codes, layer.codebooks, layer.scales, [256], None)
+    assert torch.equal(y0, want)
+    first = layer.pq_prepared
+    layer.scales.data = (layer.scales.data.float() * 2).to(torch.bfloat16)          # a new tensor
+    y1 = m.apply(layer, a.x_dev)
+    assert layer.pq_prepared is not first
+    assert torch.equal(y1, (y0.float() * 2).to(torch.bfloat16))
+    layer.codes.data, layer.codebooks.data, layer.scales.data = b.codes_dev, b.codebooks_dev, b.scales_dev
+    m.process_weights_after_loading(layer)
+    yb = m.apply(layer, a.x_dev)
+    wantb = ops.pq_gemm_packed(a.x_dev, layer.pq_packed_codes, layer.codes, layer.codebooks, layer.scales, [256], None)
+    assert torch.equal(yb, wantb) and not torch.equal(yb, y0)
+    # 3-D activations keep their leading dimensions; wrong width, dtype or device are refused
+    y3 = m.apply(layer, a.x_dev.reshape(2, 3, 512))
+    assert y3.shape == (2, 3, 256) and torch.equal(y3.reshape(6, 256), yb)
+    with pytest.raises(ValueError):
+        m.apply(layer, a.x_dev[:, :504])
+    with pytest.raises(ValueError):
+        m.apply(layer, a.x_dev.to(torch.float16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.apply(layer, a.x_dev.cpu())
+
+
 def test_ops_reject_cpu_tensors_and_bad_shapes(ops):
     p = Problem(3, 256, 8, 1, [64], 128, 2, "bf16")
     with pytest.raises(RuntimeError, match="no CPU fallback"):

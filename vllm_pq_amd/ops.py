@@ -253,14 +253,16 @@ class PackedLinear:
         if not (codebooks.is_contiguous() and scales.is_contiguous() and packed_codes.is_contiguous()):
             raise ValueError("contiguous weight tensors expected")
         self.packed, self.codes, self.codebooks, self.scales = packed_codes, codes, codebooks, scales
-        self.ptrs = (packed_codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr())
+        self.ptrs = (packed_codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), packed_codes.numel(),
+                     codebooks.numel(), scales.numel())
         self.N, self.G, self.M, self.K, self.d = N, G, M, K, d
         self.cb, self.dtype, self.tdtype = _CODE_BYTES[codes.dtype], _DTYPE[codebooks.dtype], codebooks.dtype
         self.parts, self.nparts = _lib.parts_array(parts), len(parts)
         self.device, self.features = dev, G * d
 
     def matches(self, packed_codes: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor) -> bool:
-        return self.ptrs == (packed_codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr())
+        return self.ptrs == (packed_codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), packed_codes.numel(),
+                             codebooks.numel(), scales.numel())
 
 
 def pq_gemm_packed_prepared(desc: PackedLinear, input: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
