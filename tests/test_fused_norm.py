@@ -247,3 +247,27 @@ def test_normed_gate_up_with_activation_random_shapes(i, T, H, I, bias, dtype):
         err = (got2.float() - want2.float()).abs()[ok]
         lim = (2.0 ** -6 if dtype == "bf16" else 2.0 ** -9) * want2.float().abs()[ok] + 1e-3
         assert (err <= lim).all(), f"{int((err > lim).sum())} values beyond two ulp"
+
+
+@pytest.mark.parametrize("T,H,parts", [(5, 1024, [256, 256]), (40, 2048, [512, 512]), (128, 4096, [1024, 1024]),
+                                       (23, 1536, [176, 176])])
+def test_normed_gemm_does_not_depend_on_the_batch(T, H, parts):
+    """A token's output of the GEMM behind the norm (with and without the activation) is the same bit pattern whether
+    it is computed alone or inside a batch: the block shape changes with the batch size, the order in which the
+    token's sum of squares and its partial sums are added does not."""
+    from vllm_pq_amd import ops
+    p = _layer(8000 + T, parts, H, "bf16", True)
+    pk = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    g = torch.Generator(device="cpu").manual_seed(8100 + T)
+    xw = torch.randn(T, H, generator=g).to(torch.bfloat16).to(DEV)
+    ssq = (torch.rand(H // 16, (T + 15) // 16 * 16, generator=g) * 16 + 4).to(DEV)
+    full = ops.pq_gemm_packed_normed(xw, ssq, EPS, pk, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    full_act = ops.pq_gemm_packed_normed_silu_mul(xw, ssq, EPS, pk, p.codes_dev, p.codebooks_dev, p.scales_dev, p.bias_dev)
+    for t in (0, T // 2, T - 1):
+        s1 = torch.zeros(H // 16, 16, device=DEV)
+        s1[:, 0] = ssq[:, t]
+        x1 = xw[t:t + 1].contiguous()
+        one = ops.pq_gemm_packed_normed(x1, s1, EPS, pk, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+        assert torch.equal(one.view(torch.int16), full[t:t + 1].view(torch.int16)), f"token {t}"
+        one = ops.pq_gemm_packed_normed_silu_mul(x1, s1, EPS, pk, p.codes_dev, p.codebooks_dev, p.scales_dev, p.bias_dev)
+        assert torch.equal(one.view(torch.int16), full_act[t:t + 1].view(torch.int16)), f"token {t} (activation)"
