@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
     // hand-pipelined LDS reads in the main loop: one codebook, fragments taken in pairs; d = 8, and the smaller
     // entries with one-byte codes (their images have 256 bytes per entry like d = 8's, so a gather address is the
     // code byte dropped into the lane's offset)
-    constexpr bool PIPE = (D == 8 || CB == 1) && M == 1 && WN % 2 == 0 && WT % 2 == 0 && !(ABL & (8 | 16));
+    constexpr bool PIPE = (D == 8 || CB == 1) && M == 1 && WN % 2 == 0 && WT % 2 == 0 && !(D < 8 && WT == 8) && !(ABL & (8 | 16));
     constexpr int GR = 2 * CPS;                      // LDS reads per pair of gathered fragments
     // the same format on the shapes with a single weight fragment per wave: hand-issued reads, in batches of k-steps
     constexpr bool BATCH = D == 8 && M == 1 && !PIPE && !(ABL & (8 | 16));
@@ -931,13 +931,16 @@ static int tiled_step_tiles(const GemmArgs &a, int kt) {
     return kt > tpp ? kt : tpp;
 }
 
-// Shape i for this format.  With d = 2 and d = 4 a lane holds more code or operand registers per k-step, and the
-// 256 x 256 shape would not fit the register file: its slot is a 256 x 128 tile with one k-tile per stage.  With two
-// codebooks the slot is a 256 x 256 tile whose waves take 4 weight fragments x 8 token fragments (instead of 8 x 4),
-// and the 128 x 128 shape's slot a 128 x 256 tile of 2 x 8 fragments a wave.
+// Shape i for this format.  The formats whose weight fragment costs several LDS reads or a sum (d = 4 and d = 2 with
+// one-byte codes, two codebooks) run a 256 x 256 tile whose waves take 4 weight fragments x 8 token fragments (instead
+// of 8 x 4) in the first slot, so that a fragment feeds 8 MFMAs, on the compiler-scheduled main loop (hand-pipelined,
+// its two sets of 8 activation fragments do not fit the register file); d = 2 and two codebooks also a 128 x 256 tile
+// of 2 x 8 fragments a wave in the 128 x 128 shape's slot.  With two-byte codes d = 4 and d = 2 keep a 256 x 128 tile
+// with one k-tile per stage in the first slot.
 static TiledCfg tiled_cfg(const GemmArgs &a, int i) {
     if (i == 0 && a.M == 2) return TiledCfg{256, 256, 1};
-    if (i == 2 && a.M == 2) return TiledCfg{128, 256, 1};
+    if (i == 2 && (a.M == 2 || (a.d == 2 && a.code_bytes == 1))) return TiledCfg{128, 256, 1};
+    if (i == 0 && (a.d == 4 || a.d == 2) && a.code_bytes == 1) return TiledCfg{256, 256, 1};
     if (i == 0 && (a.d == 2 || a.d == 4)) return TiledCfg{256, 128, 1};
     // the 512 x 128 shape exists for d = 8, one codebook, one-byte codes; other formats run 256 x 128 in its slot
     if (i == 6 && !(a.d == 8 && a.M == 1 && a.code_bytes == 1)) return kTiledCfgs[1];
@@ -958,7 +961,11 @@ static int choose_tiled_cfg(const GemmArgs &a) {
     // fragment feeds -- 8 in the slots of the 256 x 256 and 128 x 128 shapes (256 x 256 and 128 x 256 tiles whose
     // waves take 8 token fragments), 4 or 2 elsewhere
     static const double speed_two[kNumTiledCfgs] = {0.92, 0.59, 0.87, 0.55, 0.50, 0.31, 0.59};
-    const double *speed = a.M == 2 ? speed_two : speed_one;
+    // d = 2 with one-byte codes: four narrow gathers per weight fragment, so again the shapes whose waves take 8 token
+    // fragments (the slots of 256 x 256 and 128 x 128) are the fast ones
+    static const double speed_d2[kNumTiledCfgs] = {1.20, 0.86, 1.02, 0.83, 0.63, 0.42, 0.86};
+    const bool per_slot = a.M == 2 || (a.d == 2 && a.code_bytes == 1);
+    const double *speed = a.M == 2 ? speed_two : (a.d == 2 && a.code_bytes == 1) ? speed_d2 : speed_one;
     static const int order[kNumTiledCfgs] = {6, 0, 1, 2, 3, 4, 5};
     int best = 0;   // shape 0 takes any Kin the kernel supports
     double best_cost = -1.0;
@@ -967,7 +974,7 @@ static int choose_tiled_cfg(const GemmArgs &a) {
         if ((a.G * a.d) % (64 * tiled_step_tiles(a, c.kt))) continue;
         const long blocks = (long)tiles_in(a.parts, c.bn) * ((a.T + c.bt - 1) / c.bt);
         // (the two-codebook table is per slot; a one-codebook format whose slot holds another shape runs 256 x 128 there)
-        const double sp = (a.M == 2 || (c.bn == kTiledCfgs[i].bn && c.bt == kTiledCfgs[i].bt)) ? speed[i] : speed[1];
+        const double sp = (per_slot || (c.bn == kTiledCfgs[i].bn && c.bt == kTiledCfgs[i].bt)) ? speed[i] : speed[1];
         const double cost = (double)((blocks + 255) / 256) * c.bn * c.bt / sp;
         if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = i; }
     }
@@ -979,11 +986,12 @@ static hipError_t tiled_launch_fmt(const GemmArgs &a, hipStream_t stream) {
     switch (choose_tiled_cfg(a)) {
     case 0:
         if constexpr (M == 2) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 8, 1>(a, stream);   // 256 x 256, 8 token fragments a wave: every summed weight fragment feeds 8 MFMAs
+        else if constexpr ((D == 4 || D == 2) && sizeof(CodeT) == 1) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 8, 1>(a, stream);   // 256 x 256, 8 token fragments a wave
         else if constexpr (D == 2 || D == 4) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 1>(a, stream);   // 256 x 128
         else return tiled_launch_cfg<AT, CodeT, D, M, 4, 8, 4, 1>(a, stream);                    // 256 x 256
     case 1: return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 2>(a, stream);   // 256 x 128
     case 2:
-        if constexpr (M == 2) return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 8, 1>(a, stream);   // 128 x 256, 8 token fragments a wave
+        if constexpr (M == 2 || (D == 2 && sizeof(CodeT) == 1)) return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 8, 1>(a, stream);   // 128 x 256, 8 token fragments a wave
         else return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 4, 2>(a, stream);   // 128 x 128
     case 3: return tiled_launch_cfg<AT, CodeT, D, M, 1, 2, 4, 4>(a, stream);   // 256 x 64
     case 4: return tiled_launch_cfg<AT, CodeT, D, M, 1, 1, 4, 4>(a, stream);   // 128 x 64
