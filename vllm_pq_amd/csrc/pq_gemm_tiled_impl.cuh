@@ -931,17 +931,15 @@ static int tiled_step_tiles(const GemmArgs &a, int kt) {
     return kt > tpp ? kt : tpp;
 }
 
-// Shape i for this format.  The formats whose weight fragment costs several LDS reads or a sum (d = 4 and d = 2 with
-// one-byte codes, two codebooks) run a 256 x 256 tile whose waves take 4 weight fragments x 8 token fragments (instead
-// of 8 x 4) in the first slot, so that a fragment feeds 8 MFMAs, on the compiler-scheduled main loop (hand-pipelined,
-// its two sets of 8 activation fragments do not fit the register file); d = 2 and two codebooks also a 128 x 256 tile
-// of 2 x 8 fragments a wave in the 128 x 128 shape's slot.  With two-byte codes d = 4 and d = 2 keep a 256 x 128 tile
-// with one k-tile per stage in the first slot.
+// Shape i for this format.  The formats whose weight fragment costs several LDS reads or a sum (d = 4, d = 2, two
+// codebooks) run a 256 x 256 tile whose waves take 4 weight fragments x 8 token fragments (instead of 8 x 4) in the
+// first slot, so that a fragment feeds 8 MFMAs, on the compiler-scheduled main loop (hand-pipelined, its two sets of
+// 8 activation fragments do not fit the register file), and a 128 x 256 tile of 2 x 8 fragments a wave in the
+// 128 x 128 shape's slot.
 static TiledCfg tiled_cfg(const GemmArgs &a, int i) {
     if (i == 0 && a.M == 2) return TiledCfg{256, 256, 1};
-    if (i == 2 && (a.M == 2 || (a.d == 2 && a.code_bytes == 1))) return TiledCfg{128, 256, 1};
-    if (i == 0 && (a.d == 4 || a.d == 2) && a.code_bytes == 1) return TiledCfg{256, 256, 1};
-    if (i == 0 && (a.d == 2 || a.d == 4)) return TiledCfg{256, 128, 1};
+    if (i == 2 && (a.M == 2 || a.d < 8)) return TiledCfg{128, 256, 1};
+    if (i == 0 && (a.d == 4 || a.d == 2)) return TiledCfg{256, 256, 1};
     // the 512 x 128 shape exists for d = 8, one codebook, one-byte codes; other formats run 256 x 128 in its slot
     if (i == 6 && !(a.d == 8 && a.M == 1 && a.code_bytes == 1)) return kTiledCfgs[1];
     return kTiledCfgs[i];
@@ -961,11 +959,17 @@ static int choose_tiled_cfg(const GemmArgs &a) {
     // fragment feeds -- 8 in the slots of the 256 x 256 and 128 x 128 shapes (256 x 256 and 128 x 256 tiles whose
     // waves take 8 token fragments), 4 or 2 elsewhere
     static const double speed_two[kNumTiledCfgs] = {0.92, 0.59, 0.87, 0.55, 0.50, 0.31, 0.59};
-    // d = 2 with one-byte codes: four narrow gathers per weight fragment, so again the shapes whose waves take 8 token
-    // fragments (the slots of 256 x 256 and 128 x 128) are the fast ones
-    static const double speed_d2[kNumTiledCfgs] = {1.20, 0.86, 1.02, 0.83, 0.63, 0.42, 0.86};
-    const bool per_slot = a.M == 2 || (a.d == 2 && a.code_bytes == 1);
-    const double *speed = a.M == 2 ? speed_two : (a.d == 2 && a.code_bytes == 1) ? speed_d2 : speed_one;
+    // d = 4 and d = 2 (one- and two-byte codes): several narrow gathers per weight fragment, from an image with few
+    // copies when the codes have two bytes -- again the shapes whose waves take 8 token fragments (the slots of
+    // 256 x 256 and 128 x 128) are the fast ones.  Measured on an 8192 x 8192 layer at 4096 tokens.
+    static const double speed_d4[kNumTiledCfgs] = {1.33, 1.30, 1.13, 1.22, 0.80, 0.56, 1.30};
+    static const double speed_d2[kNumTiledCfgs] = {1.17, 0.85, 0.98, 0.81, 0.62, 0.40, 0.85};
+    static const double speed_d4w[kNumTiledCfgs] = {1.28, 0.95, 1.09, 0.87, 0.66, 0.42, 0.95};
+    static const double speed_d2w[kNumTiledCfgs] = {0.87, 0.49, 0.73, 0.48, 0.44, 0.24, 0.49};
+    const bool per_slot = a.M == 2 || a.d < 8;
+    const double *speed = a.M == 2 ? speed_two
+                          : a.d == 4 ? (a.code_bytes == 1 ? speed_d4 : speed_d4w)
+                          : a.d == 2 ? (a.code_bytes == 1 ? speed_d2 : speed_d2w) : speed_one;
     static const int order[kNumTiledCfgs] = {6, 0, 1, 2, 3, 4, 5};
     int best = 0;   // shape 0 takes any Kin the kernel supports
     double best_cost = -1.0;
@@ -986,12 +990,11 @@ static hipError_t tiled_launch_fmt(const GemmArgs &a, hipStream_t stream) {
     switch (choose_tiled_cfg(a)) {
     case 0:
         if constexpr (M == 2) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 8, 1>(a, stream);   // 256 x 256, 8 token fragments a wave: every summed weight fragment feeds 8 MFMAs
-        else if constexpr ((D == 4 || D == 2) && sizeof(CodeT) == 1) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 8, 1>(a, stream);   // 256 x 256, 8 token fragments a wave
-        else if constexpr (D == 2 || D == 4) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 1>(a, stream);   // 256 x 128
+        else if constexpr (D == 4 || D == 2) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 8, 1>(a, stream);   // 256 x 256, 8 token fragments a wave
         else return tiled_launch_cfg<AT, CodeT, D, M, 4, 8, 4, 1>(a, stream);                    // 256 x 256
     case 1: return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 2>(a, stream);   // 256 x 128
     case 2:
-        if constexpr (M == 2 || (D == 2 && sizeof(CodeT) == 1)) return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 8, 1>(a, stream);   // 128 x 256, 8 token fragments a wave
+        if constexpr (M == 2 || D < 8) return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 8, 1>(a, stream);   // 128 x 256, 8 token fragments a wave
         else return tiled_launch_cfg<AT, CodeT, D, M, 2, 2, 4, 2>(a, stream);   // 128 x 128
     case 3: return tiled_launch_cfg<AT, CodeT, D, M, 1, 2, 4, 4>(a, stream);   // 256 x 64
     case 4: return tiled_launch_cfg<AT, CodeT, D, M, 1, 1, 4, 4>(a, stream);   // 128 x 64
