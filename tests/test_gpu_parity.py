@@ -552,6 +552,27 @@ def test_k_split_many_rows_long_k(ops, T):
     assert ((y.float() - ref).abs() <= tol).all()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("fmt", [(256, 4, 1), (256, 2, 1), (16, 2, 1), (4096, 4, 1), (4096, 2, 1), (256, 8, 2)])
+@pytest.mark.parametrize("cfg", [0, 2])
+def test_tiled_kernel_wide_token_tiles(ops, monkeypatch, cfg, fmt, dtype):
+    """The 256 x 256 and 128 x 256 tiles whose waves take 8 token fragments (the formats with several gathers or a sum
+    per weight fragment), both dtypes: two token tiles, the second ragged, ragged row tiles, two partitions, bias."""
+    K, d, M = fmt
+    parts, Kin, T = [272, 144], 1024, 300
+    p = Problem(300 + cfg, K, d, M, parts, Kin, T, dtype, bias=True).to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    assert packed is not None
+    monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "tiled")
+    monkeypatch.setenv("PQ_AMD_TILED_CFG", str(cfg))
+    _lib.reload_knobs()
+    y = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    y2 = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    assert torch.equal(y, y2)
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(y), y32, dtype, f"K={K} d={d} M={M} cfg {cfg} {dtype}")
+
+
 @pytest.mark.parametrize("fmt", [(256, 8, 1), (256, 4, 1), (16, 2, 1), (4096, 8, 1), (4096, 4, 1), (256, 8, 2)])
 @pytest.mark.parametrize("cfg", range(7))
 def test_tiled_kernel_long_k_every_shape_and_format(ops, monkeypatch, fmt, cfg):
