@@ -537,6 +537,56 @@ def measure(stack, T, steps, warmup, device, dtype, world, dist_on, use_graph, s
                 split=split_times(stack, inputs, T, steps, warmup, device, dtype, dist_on, use_graph) if world > 1 or split else None)
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes of this script
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, a free local port), wait for
+    them, pass their output through and return non-zero if any of them failed.  The parent has made no GPU call
+    (importing torch makes none) and makes none: it only waits."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(s.getsockname()[1])
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout is the job's (the JSON line); the others' goes to stderr so the line stays alone
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        # a rank that dies leaves the others waiting in a collective: stop them once any has failed
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    print(f"[bench] rank {r} exited with status {code}", file=sys.stderr)
+                    rc = rc or (code if code > 0 else 1)
+            if rc:
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:       # only after a failure (or an interrupt): exactly the children started above
+                p.terminate()
+                rc = rc or 1
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -560,16 +610,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-neighbours", action="store_true", help="skip the element-wise kernels' measurement")
+    ap.add_argument("--dry-ranks", action="store_true",
+                    help="every rank prints its RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as one JSON line and exits "
+                         "without touching a GPU (exercises the rank launcher)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process never touches a GPU, it starts the N ranks and waits
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or "RANK" in os.environ
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_ranks:
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world,
+                          "master": f"{os.environ.get('MASTER_ADDR', '')}:{os.environ.get('MASTER_PORT', '')}"}),
+              flush=True)
+        return
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no ROCm device is visible")
     torch.cuda.set_device(local_rank)
