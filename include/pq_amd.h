@@ -304,8 +304,19 @@ int pq_gemm_packed_normed_silu_mul(const void *xw, int32_t T, int64_t xw_row_str
  *                    pq_ar_max_message_bytes() (2 MiB); one shot up to 256 KiB, reduce-scatter + all-gather above.
  *                    Every rank must issue the same sequence of calls (count, dtype).  Enqueues one kernel on
  *                    `stream`; no allocation, no host synchronisation: capturable into a HIP graph.
+ *   pq_ar_all_reduce_add_norm   the same sum (one shot) of a [T][H] fp16 / bf16 message with the fused residual add +
+ *                    RMSNorm that follows a row-parallel layer in a decoder block
+ *                    (vllm/model_executor/models/llama.py:272-284; layers/layernorm.py:38-74) in its epilogue:
+ *                    z = round(sum over ranks of in) + residual; residual <- round(z); xw <- round(round(z / rms(z)) * w).
+ *                    Bit-identical to pq_ar_all_reduce followed by pq_fused_add_rms_norm.  `in` is not modified and
+ *                    may not alias residual or xw.  Rows of H % 8 == 0 up to 16384 elements, T * H * 2 <= 512 KiB:
+ *                    pq_ar_add_norm_supported(T, H, dtype) says whether a problem is taken (larger batches run the
+ *                    two steps).  Same calling rules as pq_ar_all_reduce.
+ *   pq_ar_set_timeout_ms   how long a wait for a peer's flag lasts before it gives up (default 30 s)
  *   pq_ar_status     synchronous check after the stream has been synchronised: non-zero when a wait for a peer's
- *                    flag gave up (2 s), after which the communicator must not be used any more
+ *                    flag gave up.  A call whose wait gave up has filled its part of every output with NaN (all bits
+ *                    set) instead of a sum, so the failure cannot go unnoticed downstream; the status stays set and
+ *                    the communicator must not be used any more (the ranks' call counters may have come apart).
  * These calls are the only ones in the library that allocate (pq_ar_alloc) or keep pointers (the communicator).
  * Return 0 or a pq_status code; pq_ar_last_error() has the text.
  */
@@ -321,6 +332,10 @@ int pq_ar_close(void *peer_buffer);
 int pq_ar_create(int32_t rank, int32_t world, void *const *buffers, void **comm);
 int pq_ar_destroy(void *comm);
 int pq_ar_all_reduce(void *comm, const void *in, void *out, int64_t count, int32_t dtype, void *stream);
+int pq_ar_add_norm_supported(int32_t T, int32_t H, int32_t dtype);
+int pq_ar_all_reduce_add_norm(void *comm, const void *in, int32_t T, int32_t H, int32_t dtype, void *residual,
+                              const void *norm_weight, float eps, void *xw, void *stream);
+int pq_ar_set_timeout_ms(void *comm, int64_t ms);
 int pq_ar_status(void *comm);
 
 #ifdef __cplusplus

@@ -38,10 +38,23 @@ def pytest_sessionstart(session):
         port = s.getsockname()[1]
     out = tempfile.mkdtemp(prefix="pq_xgmi_")
     world = 2
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "xgmi_worker.py"), str(r), str(world),
-                               str(port), out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-             for r in range(world)]
+    # the workers' stdout and stderr go to files the test prints when a rank leaves no verdict (a crash)
+    procs = []
+    for r in range(world):
+        log = open(os.path.join(out, f"rank{r}.log"), "wb")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "xgmi_worker.py"), str(r), str(world),
+                                       str(port), out], stdout=log, stderr=subprocess.STDOUT))
+        log.close()
     XGMI_JOB = {"procs": procs, "dir": out, "world": world}
+
+
+def xgmi_worker_log(rank, tail=4000):
+    """The end of what worker `rank` wrote to stdout / stderr."""
+    try:
+        with open(os.path.join(XGMI_JOB["dir"], f"rank{rank}.log"), "rb") as f:
+            return f.read()[-tail:].decode("utf-8", "replace")
+    except (OSError, TypeError):
+        return "(no log)"
 
 
 def pytest_sessionfinish(session, exitstatus):

@@ -237,3 +237,19 @@ def test_public_wrappers_route_fake_tensors_through_the_ops():
         assert ops.pq_dequant(codes, cb, [64, 32]).shape == (96, 64)
         out = torch.empty(7, 32, dtype=torch.bfloat16, device="cuda")
         assert ops.silu_and_mul(out, x) is None
+
+
+def test_rows_helper_refuses_tensors_it_would_have_to_copy():
+    """The residual of the fused add + norm is updated in place through a 2-D view: a tensor whose leading dimensions
+    do not collapse (a slice along the sequence dimension) must be refused, not silently copied."""
+    import pytest
+    import torch
+    from vllm_pq_amd import ops
+    full = torch.zeros(2, 6, 64, dtype=torch.bfloat16)
+    ok = ops._rows16(full, 64, "residual")
+    assert ok.shape == (12, 64) and ok.data_ptr() == full.data_ptr()
+    sliced = full[:, :4, :]                       # [2, 4, 64] with a gap between the two batches
+    with pytest.raises(ValueError, match="without a copy"):
+        ops._rows16(sliced, 64, "residual")
+    with pytest.raises(ValueError):
+        ops._rows16(torch.zeros(3, 32, dtype=torch.bfloat16), 64, "residual")

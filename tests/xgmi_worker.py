@@ -95,7 +95,66 @@ def main():
                 assert torch.equal(out.cpu(), want2)
         ar.check()
         res["checks"].append("graph replay")
-        ps.destroy_model_parallel()
+        # the sum with the decoder block's residual add + RMSNorm in its epilogue: bit for bit the all-reduce followed
+        # by the library's fused_add_rms_norm (itself pinned to the reference's forward_native by tests/test_layers.py)
+        from vllm_pq_amd import ops
+        for ci, (T, H, dt) in enumerate([(16, 4096, torch.bfloat16), (1, 4096, torch.float16), (5, 8192, torch.bfloat16),
+                                         (33, 1024, torch.bfloat16), (64, 4096, torch.bfloat16), (3, 16384, torch.float16),
+                                         (7, 1000, torch.bfloat16)]):
+            xs = inputs(world, (T, H), dt, 500 + ci)
+            g = torch.Generator().manual_seed(900 + ci)
+            res0 = torch.randn(T, H, generator=g).to(dt).to(dev)
+            w = (torch.rand(H, generator=g) + 0.5).to(dt).to(dev)
+            mine = xs[rank].to(dev)
+            assert ar.add_norm_supported(mine, res0), (T, H, dt)
+            res_f = res0.clone()
+            keep = mine.clone()
+            xw = ps.tensor_model_parallel_all_reduce_add_norm(mine, res_f, w, 1e-5)
+            torch.cuda.synchronize()
+            assert torch.equal(mine, keep)                      # the fused call leaves its input alone
+            summed = ps.tensor_model_parallel_all_reduce(mine)
+            res_u = res0.clone()
+            ops.fused_add_rms_norm(summed, res_u, w, 1e-5)
+            torch.cuda.synchronize()
+            assert torch.equal(res_f.view(torch.int16), res_u.view(torch.int16)), f"residual {T}x{H} {dt}"
+            bad = (xw.view(torch.int16) != summed.view(torch.int16)).nonzero()
+            assert bad.numel() == 0, (f"normed {T}x{H} {dt}: {bad.shape[0]} differ, first at {bad[0].tolist()}: "
+                                      f"{xw[tuple(bad[0].tolist())].item()} vs {summed[tuple(bad[0].tolist())].item()}; "
+                                      f"rows {sorted(set(bad[:, 0].tolist()))[:8]} cols {bad[:8, 1].tolist()}")
+        # not taken (too large for one shot / rows not a multiple of 8): the two steps run, same interface
+        big = torch.randn(256, 4096).to(torch.bfloat16).to(dev)
+        assert not ar.add_norm_supported(big, torch.empty_like(big))
+        rb = torch.zeros_like(big)
+        out = ps.tensor_model_parallel_all_reduce_add_norm(big.clone(), rb, torch.ones(4096, dtype=torch.bfloat16, device=dev), 1e-5)
+        torch.cuda.synchronize()
+        assert out.shape == big.shape and torch.isfinite(out.float()).all()
+        ar.check()
+        res["checks"].append("fused add + norm")
+
+        # LAST (it ruins the communicator): a peer that never arrives.  Rank 0 alone issues a call with a short
+        # timeout: its output must be NaN everywhere, never a stale sum, and the status must say so.
+        dist.barrier()
+        if rank == 0:
+            ar.set_timeout_ms(200)
+            lone = torch.ones(16, 4096, dtype=torch.bfloat16, device=dev)
+            got = ar.all_reduce(lone)
+            r2 = torch.zeros(4, 4096, dtype=torch.bfloat16, device=dev)
+            xw2 = ar.all_reduce_add_norm(lone[:4].contiguous(), r2, torch.ones(4096, dtype=torch.bfloat16, device=dev), 1e-5)
+            torch.cuda.synchronize()
+            assert torch.isnan(got.float()).all(), "a timed-out all-reduce must not return a sum"
+            assert torch.isnan(xw2.float()).all() and torch.isnan(r2.float()).all()
+            try:
+                ar.check()
+                raise AssertionError("check() did not report the timeout")
+            except RuntimeError as e:
+                assert "timed out" in str(e)
+        dist.barrier()
+        try:
+            ps.destroy_model_parallel()             # close() reports the timeout once more on the rank that saw it
+            assert rank != 0, "close() did not report the timeout"
+        except RuntimeError as e:
+            assert rank == 0 and "timed out" in str(e)
+        res["checks"].append("timeout poisons the output")
         dist.destroy_process_group()
         res["ok"] = True
     except BaseException as e:  # noqa: BLE001 - the parent reports it

@@ -22,7 +22,8 @@ EXPORTS = ("pq_version", "pq_caps", "pq_last_error", "pq_dequant", "pq_gemm_work
            "pq_ar_max_message_bytes", "pq_ar_alloc", "pq_ar_free", "pq_ar_open", "pq_ar_close", "pq_ar_create",
            "pq_ar_destroy", "pq_ar_all_reduce", "pq_ar_status", "pq_gemm_packed_add_norm_supported",
            "pq_gemm_packed_normed_supported", "pq_gemm_packed_add_norm", "pq_gemm_packed_normed",
-           "pq_gemm_packed_normed_silu_mul_supported", "pq_gemm_packed_normed_silu_mul")
+           "pq_gemm_packed_normed_silu_mul_supported", "pq_gemm_packed_normed_silu_mul", "pq_ar_add_norm_supported",
+           "pq_ar_all_reduce_add_norm", "pq_ar_set_timeout_ms")
 
 _lock = threading.Lock()
 _lib = None
@@ -123,7 +124,10 @@ def load():
         L.pq_ar_destroy.argtypes = [vp]
         L.pq_ar_all_reduce.argtypes = [vp, vp, vp, i64, i32, vp]
         L.pq_ar_status.argtypes = [vp]
-        for fn in ("pq_ar_alloc", "pq_ar_free", "pq_ar_open", "pq_ar_close", "pq_ar_create", "pq_ar_destroy",
+        L.pq_ar_add_norm_supported.argtypes = [i32, i32, i32]
+        L.pq_ar_all_reduce_add_norm.argtypes = [vp, vp, i32, i32, i32, vp, vp, f32, vp, vp]
+        L.pq_ar_set_timeout_ms.argtypes = [vp, i64]
+        for fn in ("pq_ar_add_norm_supported", "pq_ar_all_reduce_add_norm", "pq_ar_set_timeout_ms", "pq_ar_alloc", "pq_ar_free", "pq_ar_open", "pq_ar_close", "pq_ar_create", "pq_ar_destroy",
                    "pq_ar_all_reduce", "pq_ar_status"):
             getattr(L, fn).restype = ctypes.c_int
         if L.pq_version() != PQ_ABI_VERSION:

@@ -163,6 +163,15 @@ struct Act<fp16_t> {
     }
 };
 
+// An fp32 value as it stands in a register.  The compiler may otherwise merge the arithmetic that produced it with a
+// following conversion to fp16 into one v_fma_mix instruction, which rounds the exact result ONCE; where the reference
+// rounds to fp32 first and to the act dtype second (RMSNorm.forward_native, layernorm.py:66-70), the two can differ
+// in the last bit.
+__device__ __forceinline__ float rounded_f32(float f) {
+    asm("" : "+v"(f));
+    return f;
+}
+
 // Unsigned index of a signed stored code: value mod K with K a power of two (aqlm.py:32-34).
 template <typename CodeT>
 __device__ inline uint32_t code_index(CodeT c, uint32_t kmask) {

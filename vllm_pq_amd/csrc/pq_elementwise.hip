@@ -133,7 +133,7 @@ __global__ __launch_bounds__(THREADS) void rms_norm_kernel(const uint16_t *x, in
                 uint32_t packed = 0;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const float n = Act<AT>::to_f32(Act<AT>::from_f32(z[i][2 * w + h] * rs));
+                    const float n = Act<AT>::to_f32(Act<AT>::from_f32(rounded_f32(z[i][2 * w + h] * rs)));
                     packed |= (uint32_t)Act<AT>::from_f32(n * Act<AT>::to_f32((uint16_t)(wv[w] >> (16 * h)))) << (16 * h);
                 }
                 o[w] = packed;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(EW_THREADS) void rms_norm_scalar_kernel(const uint1
     }
     const float rs = rsqrtf(block_sum<EW_THREADS>(ss, s_part) / (float)H + eps);
     for (int j = threadIdx.x; j < H; j += EW_THREADS) {
-        const float n = Act<AT>::to_f32(Act<AT>::from_f32(s_row[j] * rs));
+        const float n = Act<AT>::to_f32(Act<AT>::from_f32(rounded_f32(s_row[j] * rs)));
         out[(size_t)t * out_stride + j] = Act<AT>::from_f32(n * Act<AT>::to_f32(weight[j]));
     }
 }

@@ -76,11 +76,17 @@ DecodeGeom choose_decode_geom(const GemmArgs &a) {
     g.wk_log2 = g.cpb >= 5 ? 3 : g.cpb >= 3 ? 2 : g.cpb >= 2 ? 1 : 0;
     const int WK = 1 << g.wk_log2;
     double best = -1.0;
-    g.nf = 1;
+    g.nf = 0;                     // not taken unless a shape passes the checks below
     g.waves = WK;
+    const int tgroups = (a.T + 15) / 16;
+    // a K-split launch has one arrival counter per tile and token group in the workspace's counter area
+    auto counters_fit = [&](int wr, int nf) {
+        return g.ksplit == 1 || (long)tiles_in(a.parts, wr * nf * 16) * tgroups * 4 <= (long)WS_COUNTER_BYTES;
+    };
     if (knobs().decode_waves) {   // PQ_AMD_DECODE_CFG = "WAVESxNF", for tuning
         const int w = knobs().decode_waves, nf = knobs().decode_nf;
-        if (w % WK == 0 && w >= WK && w <= DC_MAX_WAVES && !((w / WK) & (w / WK - 1)) && nf >= 1 && nf <= WK && nf * g.c <= DC_UMAX) {
+        if (w % WK == 0 && w >= WK && w <= DC_MAX_WAVES && !((w / WK) & (w / WK - 1)) && nf >= 1 && nf <= WK && nf * g.c <= DC_UMAX &&
+            counters_fit(w / WK, nf)) {
             g.nf = nf;
             g.waves = w;
             return g;
@@ -88,9 +94,8 @@ DecodeGeom choose_decode_geom(const GemmArgs &a) {
     }
     for (int wr = 1; wr * WK <= DC_MAX_WAVES; wr *= 2) {
         for (int nf = 1; nf <= WK && nf * g.c <= DC_UMAX; ++nf) {
-            const int tgroups = (a.T + 15) / 16;
             const long tiles = (long)tiles_in(a.parts, wr * nf * 16) * g.ksplit * tgroups;
-            if (g.ksplit > 1 && tiles / g.ksplit * 4 > (long)WS_COUNTER_BYTES) continue;   // one counter per tile and token group
+            if (!counters_fit(wr, nf)) continue;
             const double rounds = (double)((tiles + 255) / 256);
             // fixed: launch ramp, image, epilogue; per unit of a wave about 0.3 us; blocks of few waves share a CU
             const double cost = rounds * (3.0 + 0.3 * nf * g.c) + (tiles < 256 ? 0.002 * (256 - tiles) : 0.0) * nf * g.c;
@@ -164,23 +169,25 @@ static hipError_t launch_decode_at(const GemmArgs &a, const DecodeGeom &g, hipSt
     p.tmap = make_tile_map(tparts, rows);
     const dim3 grid(tiles_in(tparts, rows), g.ksplit, (a.T + 15) / 16);
     const size_t lds = dc_lds_bytes(g.waves, p.img_bytes);
-    auto launch = [&](auto kern) -> hipError_t {
-        static std::atomic<bool> attr_set[64];   // per device: more than the default 64 KiB of LDS
+    // More than the default 64 KiB of LDS needs the opt-in once per kernel VARIANT and device: the variants share
+    // one function-pointer type (and so one instantiation of this lambda), hence a flag array per variant index.
+    auto launch = [&](auto kern, int variant) -> hipError_t {
+        static std::atomic<bool> attr_set[5][64];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-        if (!attr_set[dev].load(std::memory_order_acquire)) {
+        if (!attr_set[variant][dev].load(std::memory_order_acquire)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)dc_lds_bytes(DC_MAX_WAVES, 65536));
             if (e != hipSuccess) return e;
-            attr_set[dev].store(true, std::memory_order_release);
+            attr_set[variant][dev].store(true, std::memory_order_release);
         }
         hipLaunchKernelGGL(kern, grid, dim3(g.waves * 64), lds, stream, p);
         return hipGetLastError();
     };
-    if (act) return role == 2 ? launch(gemm_decode_kernel<AT, false, 0, 2, true>) : launch(gemm_decode_kernel<AT, false, 0, 0, true>);
-    if (role == 1) return launch(gemm_decode_kernel<AT, false, 0, 1>);
-    if (role == 2) return launch(gemm_decode_kernel<AT, false, 0, 2>);
-    return launch(gemm_decode_kernel<AT>);
+    if (act) return role == 2 ? launch(gemm_decode_kernel<AT, false, 0, 2, true>, 4) : launch(gemm_decode_kernel<AT, false, 0, 0, true>, 3);
+    if (role == 1) return launch(gemm_decode_kernel<AT, false, 0, 1>, 1);
+    if (role == 2) return launch(gemm_decode_kernel<AT, false, 0, 2>, 2);
+    return launch(gemm_decode_kernel<AT>, 0);
 }
 
 // Geometry of the fused gate_up + activation launch: 8 waves, as many along K as there are chunks, nf gate fragments

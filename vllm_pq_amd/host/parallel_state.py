@@ -41,8 +41,15 @@ def enable_xgmi_all_reduce(max_bytes: Optional[int] = None) -> bool:
     global _XGMI_AR
     if _TP_SIZE < 2 or _TP_SIZE > 8 or not torch.cuda.is_available():
         return False
-    from .xgmi_all_reduce import XgmiAllReduce
-    _XGMI_AR = XgmiAllReduce(_TP_GROUP, max_bytes)
+    from .xgmi_all_reduce import XgmiAllReduce, peers_reachable
+    # one host, peer access between every pair of devices -- agreed on by all ranks; otherwise RCCL stays the path
+    if not peers_reachable(_TP_GROUP):
+        return False
+    try:
+        _XGMI_AR = XgmiAllReduce(_TP_GROUP, max_bytes)
+    except RuntimeError:        # raised on every rank together (a buffer could not be allocated or mapped)
+        _XGMI_AR = None
+        return False
     return True
 
 
@@ -78,6 +85,21 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor, in_place: bool = Fals
     out = input_ if in_place and input_.is_contiguous() else input_.clone(memory_format=torch.contiguous_format)
     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=_TP_GROUP)
     return out
+
+
+def tensor_model_parallel_all_reduce_add_norm(input_: torch.Tensor, residual: torch.Tensor, norm_weight: torch.Tensor,
+                                             eps: float) -> torch.Tensor:
+    """The sum of a row-parallel layer's partial outputs over the TP group followed by the decoder block's fused
+    residual add + RMSNorm (RowParallelLinear.forward's all-reduce, linear.py:1212-1213, then
+    RMSNorm.forward(x, residual), models/llama.py:272-284): `residual` becomes sum + residual in place, the
+    normalised tensor is returned.  One launch of the peer-buffer all-reduce where it takes the batch (decode
+    sizes); otherwise -- and with one rank -- the collective and the norm kernel, with the same values."""
+    from .. import ops
+    if _TP_SIZE > 1 and _XGMI_AR is not None and _XGMI_AR.add_norm_supported(input_, residual):
+        return _XGMI_AR.all_reduce_add_norm(input_, residual, norm_weight, eps)
+    x = tensor_model_parallel_all_reduce(input_, in_place=True)
+    ops.fused_add_rms_norm(x, residual, norm_weight, eps)
+    return x
 
 
 def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:

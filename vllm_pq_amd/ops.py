@@ -502,7 +502,13 @@ def gemm_normed_supported(T: int, codes: torch.Tensor, codebooks: torch.Tensor, 
 
 
 def _rows16(t: torch.Tensor, cols: int, what: str) -> torch.Tensor:
-    t2 = t.reshape(-1, t.shape[-1])
+    # a VIEW of the caller's tensor (the residual is updated in place through it): leading dimensions that do not
+    # collapse -- a slice along the sequence dimension of a 3-D tensor -- are refused rather than silently copied
+    try:
+        t2 = t.view(-1, t.shape[-1])
+    except RuntimeError:
+        raise ValueError(f"{what}: the leading dimensions must collapse into rows without a copy "
+                         f"(shape {tuple(t.shape)}, strides {tuple(t.stride())})") from None
     if t2.shape[-1] != cols or t2.stride(-1) != 1 or t2.data_ptr() % 16 or t2.stride(0) % 8:
         raise ValueError(f"{what}: [tokens, {cols}] with unit column stride, 16-byte aligned rows expected")
     return t2
