@@ -17,7 +17,7 @@ from vllm_pq_amd import _lib, ops  # noqa: E402
 from sweep import MODEL_SHAPES  # noqa: E402
 
 STREAM = ["1x1", "2x1", "4x1", "7x1", "8x1", "4x2", "7x2", "2x4", "4x4"]
-KNOBS = ("PQ_AMD_FORCE_KERNEL", "PQ_AMD_STREAM_CFG", "PQ_AMD_STREAM_KSPLIT", "PQ_AMD_TILED_CFG")
+KNOBS = ("PQ_AMD_FORCE_KERNEL", "PQ_AMD_STREAM_CFG", "PQ_AMD_STREAM_KSPLIT", "PQ_AMD_TILED_CFG", "PQ_AMD_WIDE_CFG")
 
 
 def set_env(**kw):
@@ -101,6 +101,25 @@ def main():
                     t = time_call(fn, use)
                     if t is not None:
                         cands["decode"] = t
+            if T > 16 and K <= 256 and d == 8 and G % 64 == 0 and G // 64 <= 8:
+                # the mid-batch kernel: its own choice of block shape, and every shape whose grid is within two passes of the chip
+                set_env(PQ_AMD_FORCE_KERNEL="wide")
+                if ops.gemm_kernel_name(T, N, G, 1, K, d, cbytes, dt, parts, packed=True) == "mfma_wide_packed":
+                    t = time_call(fn, use)
+                    if t is not None:
+                        cands["wide"] = t
+                    nch = G // 64
+                    wr = 8 >> (3 if nch >= 5 else 2 if nch >= 3 else 1 if nch >= 2 else 0)
+                    for nf in (1, 2, 3, 4):
+                        for rounds in range(1, 64 // (wr * nf) + 1):
+                            rows_blk = wr * rounds * nf * 16
+                            blocks = sum(-(-p_ // rows_blk) for p_ in parts) * (-(-T // 32))
+                            if blocks > 512 or (blocks < 128 and rounds > 1):
+                                continue
+                            set_env(PQ_AMD_FORCE_KERNEL="wide", PQ_AMD_WIDE_CFG=f"{nf}x{rounds}")
+                            t = time_call(fn, use)
+                            if t is not None:
+                                cands[f"wide {nf}x{rounds}"] = t
             if T > 16:
                 for i in range(7):
                     set_env(PQ_AMD_FORCE_KERNEL="tiled", PQ_AMD_TILED_CFG=i)
@@ -110,10 +129,17 @@ def main():
             set_env()
             default = min(default, time_call(fn, use))      # before and after the candidates: clocks and caches settle
             best = min(cands, key=cands.get)
+            wides = {k: v for k, v in cands.items() if k.startswith("wide")}
+            others = {k: v for k, v in cands.items() if not k.startswith("wide")}
+            bw = min(wides, key=wides.get) if wides else ""
+            bo = min(others, key=others.get) if others else ""
             rows.append(dict(shape=name, T=T, default_us=round(default, 2), best_us=round(cands[best], 2), best=best,
-                             regret=round(default / cands[best] - 1, 3)))
+                             regret=round(default / cands[best] - 1, 3), wide_us=round(wides.get("wide", 0.0), 2),
+                             best_wide=bw, best_wide_us=round(wides[bw], 2) if bw else 0.0, best_other=bo,
+                             best_other_us=round(others[bo], 2) if bo else 0.0))
             print(f"{name:16s} T={T:5d} default {default:8.2f} us   best {cands[best]:8.2f} us ({best:16s}) "
-                  f"regret {100 * (default / cands[best] - 1):5.1f} %", flush=True)
+                  f"regret {100 * (default / cands[best] - 1):5.1f} %   wide {wides.get('wide', 0):7.2f}  best wide {bw} "
+                  f"{wides.get(bw, 0):7.2f}  best other {bo} {others.get(bo, 0):7.2f}", flush=True)
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     with open(args.out, "w", newline="") as f:
         wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))

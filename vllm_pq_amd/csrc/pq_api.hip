@@ -57,7 +57,7 @@ int check_format(const char *fn, const int32_t *part_sizes, int num_parts, int N
     return PQ_OK;
 }
 
-enum Kernel { K_GENERIC = 0, K_STREAM = 1, K_TILED = 2, K_DECODE = 3 };
+enum Kernel { K_GENERIC = 0, K_STREAM = 1, K_TILED = 2, K_DECODE = 3, K_WIDE = 4 };
 
 Kernel choose(const pq::GemmArgs &a) {
     const int force = pq::knobs().force_kernel;
@@ -65,7 +65,17 @@ Kernel choose(const pq::GemmArgs &a) {
     if (force == K_STREAM && pq::gemm_stream_supported(a)) return K_STREAM;
     if (force == K_TILED && pq::gemm_tiled_supported(a)) return K_TILED;
     if (force == K_DECODE && pq::gemm_decode_supported(a)) return K_DECODE;
+    if (force == K_WIDE && pq::gemm_wide_supported(a)) return K_WIDE;
     if (force < 0 && pq::gemm_decode_preferred(a)) return K_DECODE;
+    // Mid-size batches of 5 to 20 GFLOP on layers of at least five 512-feature chunks (every wave of a block gets a
+    // chunk): the mid-batch kernel.  Measured on the MI355X against every tile shape of the other kernels
+    // (tools/autotune.py --full): ahead by 7 - 18 % in that range -- blocks of 8 to 16 units a wave, one pass over the chip
+    // --, behind the decode kernel's token groups below it (a launch is then mostly its fixed phases, and 16-token blocks
+    // take in half the activations) and behind the tiled kernel above it (long main loops at a higher MFMA rate).
+    if (force < 0 && a.T > 16 && a.G / 64 >= 5 && pq::gemm_wide_supported(a)) {
+        const double flops = 2.0 * (double)a.T * (double)a.N * (double)a.G * (double)a.d;
+        if (flops >= 4.5e9 && flops <= 2.1e10) return K_WIDE;
+    }
     const bool st = pq::gemm_stream_supported(a);
     const bool ti = pq::gemm_tiled_supported(a);
     if (ti && st && a.T > 16) {
@@ -101,13 +111,14 @@ Kernel choose(const pq::GemmArgs &a) {
 namespace pq {
 
 static Knobs read_knobs() {
-    Knobs k{-1, 0, 0, 0, -1, 0, 0, 0};
+    Knobs k{-1, 0, 0, 0, -1, 0, 0, 0, 0, 0};
     const char *e = getenv("PQ_AMD_FORCE_KERNEL");
     if (e && *e) {
         if (!strcmp(e, "generic")) k.force_kernel = K_GENERIC;
         else if (!strcmp(e, "stream")) k.force_kernel = K_STREAM;
         else if (!strcmp(e, "tiled")) k.force_kernel = K_TILED;
         else if (!strcmp(e, "decode")) k.force_kernel = K_DECODE;
+        else if (!strcmp(e, "wide")) k.force_kernel = K_WIDE;
     }
     e = getenv("PQ_AMD_STREAM_CFG");
     if (e && *e && sscanf(e, "%dx%d", &k.stream_nf, &k.stream_tf) != 2) k.stream_nf = k.stream_tf = 0;
@@ -119,6 +130,8 @@ static Knobs read_knobs() {
     if (e && *e) k.tiled_slots = atoi(e);
     e = getenv("PQ_AMD_DECODE_CFG");
     if (e && *e && sscanf(e, "%dx%d", &k.decode_waves, &k.decode_nf) != 2) k.decode_waves = k.decode_nf = 0;
+    e = getenv("PQ_AMD_WIDE_CFG");
+    if (e && *e && sscanf(e, "%dx%d", &k.wide_nf, &k.wide_rounds) != 2) k.wide_nf = k.wide_rounds = 0;
     return k;
 }
 static Knobs g_knobs = read_knobs();   // at library load
@@ -233,6 +246,7 @@ static int run_gemm(const char *fn, bool packed, const void *x, int32_t T, int64
     case K_TILED: e = pq::launch_gemm_tiled(a, s); break;
     case K_STREAM: e = pq::launch_gemm_stream(a, s); break;
     case K_DECODE: e = pq::launch_gemm_decode(a, s); break;
+    case K_WIDE: e = pq::launch_gemm_wide(a, s); break;
     default: e = pq::launch_gemm_generic(a, s); break;
     }
     if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "%s: %s", fn, hipGetErrorString(e));
@@ -342,7 +356,7 @@ int pq_gemm_kernel_name(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, i
     a.workspace_bytes = pq::WS_COUNTER_BYTES + pq::WS_PARTIAL_BYTES;
     if (a.packed && !pq::packable(a.parts, G, d, K, M, code_bytes))
         return fail(PQ_ERR_UNSUPPORTED, "pq_gemm_kernel_name: this format has no packed layout");
-    static const char *names[] = {"generic", "mfma_stream", "mfma_tiled", "mfma_decode"};
+    static const char *names[] = {"generic", "mfma_stream", "mfma_tiled", "mfma_decode", "mfma_wide"};
     snprintf(buf, buf_len, "%s%s", names[choose(a)], a.packed ? "_packed" : "");
     return PQ_OK;
 }

@@ -102,6 +102,13 @@ bool gemm_decode_norm_supported(const GemmArgs &a);
 bool gemm_decode_act_supported(const GemmArgs &a);
 hipError_t launch_gemm_decode_act(const GemmArgs &a, hipStream_t stream);
 
+// Mid-size batches (32 tokens per block over gridDim.z, any number of rows per block in rounds; d = 8, one codebook of
+// up to 256 entries, one-byte packed codes, at most 8 chunks of 512 features): pq_gemm_wide_impl.cuh.
+struct WideGeom { int nf, rounds, wk_log2; };   // fragments per wave and round, rounds per block, log2 of the waves along K
+bool gemm_wide_supported(const GemmArgs &a);
+WideGeom choose_wide_geom(const GemmArgs &a, double *model_us);   // *model_us (optional): modelled launch duration
+hipError_t launch_gemm_wide(const GemmArgs &a, hipStream_t stream);
+
 // Load-time re-layout of the codes for the MFMA kernels.
 bool stream_format_supported(int d, int K, int M, int code_bytes);
 bool packable(const Parts &parts, int G, int d, int K, int M, int code_bytes);

@@ -1,11 +1,12 @@
 // Diagnostic knobs of the dispatch (tests, tuning tools): the PQ_AMD_* environment variables, read ONCE when the
 // library is first used and again only when pq_debug_reload_knobs() is called -- never per launch.
-//   PQ_AMD_FORCE_KERNEL   "generic" | "stream" | "tiled" | "decode"
+//   PQ_AMD_FORCE_KERNEL   "generic" | "stream" | "tiled" | "decode" | "wide"
 //   PQ_AMD_STREAM_CFG     "NFxTF" tile of the streaming kernel
 //   PQ_AMD_STREAM_KSPLIT  blocks per tile along K of the streaming kernel
 //   PQ_AMD_TILED_CFG      tile shape index of the tiled kernel
 //   PQ_AMD_TILED_SLOTS    blocks per XCD of the tiled kernel
 //   PQ_AMD_DECODE_CFG     "WAVESxNF" block shape of the decode kernel
+//   PQ_AMD_WIDE_CFG       "NFxROUNDS" block shape of the mid-batch kernel
 #pragma once
 
 namespace pq {
@@ -17,6 +18,7 @@ struct Knobs {
     int tiled_cfg;         // -1: none
     int tiled_slots;       // 0: none
     int decode_waves, decode_nf;   // 0: none
+    int wide_nf, wide_rounds;      // 0: none
 };
 
 const Knobs &knobs();      // thread-safe; the first call reads the environment
