@@ -687,3 +687,12 @@ def test_row_length_not_a_multiple_of_8_keeps_the_reference_layout(ops):
     y = m.apply(layer, p.x_dev, p.bias_dev)
     _, y32 = p.oracle_gemm(order=2)
     assert_close_to_exact(bits_of(y), y32, "bf16", "unpacked fallback")
+
+
+def test_min_capability_passes_on_this_device():
+    """vLLM compares QuantizationConfig.get_min_capability() with major * 10 + minor of the device
+    (vllm/config.py:3333-3342; the ROCm platform reports torch.cuda.get_device_capability): the MI355X must pass."""
+    from vllm_pq_amd import PQConfig
+    major, minor = torch.cuda.get_device_capability(0)
+    assert major * 10 + minor >= PQConfig.get_min_capability(), (major, minor)
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName

@@ -1,6 +1,8 @@
 """Picks the interface classes the PQ method derives from: vLLM's own when vLLM is importable (the
-drop-in case), this package's stand-alone mirror otherwise."""
-try:  # pragma: no cover - vLLM is not installed in the build image
+drop-in case), this package's stand-alone mirror otherwise.  The vLLM branch is exercised against the reference's
+real registry, base classes and parallel linear layers by tests/golden/make_golden_binding.py (re-run by
+tests/test_binding_golden.py wherever the reference tree is present)."""
+try:
     from vllm.model_executor.layers.linear import LinearBase, LinearMethodBase
     from vllm.model_executor.layers.quantization import (QUANTIZATION_METHODS, get_quantization_config,
                                                          register_quantization_config)

@@ -357,7 +357,23 @@ int pq_gemm_kernel_name(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, i
     if (a.packed && !pq::packable(a.parts, G, d, K, M, code_bytes))
         return fail(PQ_ERR_UNSUPPORTED, "pq_gemm_kernel_name: this format has no packed layout");
     static const char *names[] = {"generic", "mfma_stream", "mfma_tiled", "mfma_decode", "mfma_wide"};
-    snprintf(buf, buf_len, "%s%s", names[choose(a)], a.packed ? "_packed" : "");
+    const Kernel k = choose(a);
+    int n = snprintf(buf, buf_len, "%s%s", names[k], a.packed ? "_packed" : "");
+    // a caller with a long buffer (tuning tools) also gets the launch geometry behind the name
+    if (buf_len >= 128 && n > 0 && (size_t)n < buf_len) {
+        if (k == K_STREAM) {
+            double us = 0.0;
+            const pq::StreamCfg c = pq::choose_stream_cfg(a, &us);
+            snprintf(buf + n, buf_len - n, " %dx%d ks%d model %.1f us", c.nf, c.tf, c.ksplit, us);
+        } else if (k == K_WIDE) {
+            double us = 0.0;
+            const pq::WideGeom g = pq::choose_wide_geom(a, &us);
+            snprintf(buf + n, buf_len - n, " %dx%d model %.1f us", g.nf, g.rounds, us);
+        } else if (k == K_DECODE) {
+            const pq::DecodeGeom g = pq::choose_decode_geom(a);
+            snprintf(buf + n, buf_len - n, " %dx%d ks%d model %.1f us", g.waves, g.nf, g.ksplit, pq::decode_model_us(a));
+        }
+    }
     return PQ_OK;
 }
 

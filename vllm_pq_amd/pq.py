@@ -325,7 +325,7 @@ def register() -> None:
     platform's allow-list, which otherwise rejects unknown methods (vllm/platforms/rocm.py:108-111)."""
     if PQ_METHOD_NAME not in QUANTIZATION_METHODS:
         register_quantization_config(PQ_METHOD_NAME)(PQConfig)
-    try:  # pragma: no cover - needs vLLM
+    try:
         from vllm.platforms.rocm import RocmPlatform
         if PQ_METHOD_NAME not in RocmPlatform.supported_quantization:
             RocmPlatform.supported_quantization.append(PQ_METHOD_NAME)
