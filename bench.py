@@ -265,19 +265,37 @@ def time_dominant_kernel(stack, inputs, name, reps):
 
 
 def host_cpu():
-    """Model string and the vector ISA levels of the host CPU (what the torch-CPU operators can use)."""
+    """Model string, vector ISA levels and topology of the host CPU (what the torch-CPU operators can use): sockets,
+    physical cores and logical CPUs of the machine from /proc/cpuinfo, and the logical CPUs this process may run on."""
     model, flags = "unknown", set()
+    phys, logical, sockets = set(), 0, set()
     try:
         with open("/proc/cpuinfo") as f:
+            pid = cid = None
             for line in f:
                 if line.startswith("model name") and model == "unknown":
                     model = line.split(":", 1)[1].strip()
                 elif line.startswith("flags") and not flags:
                     flags = set(line.split(":", 1)[1].split())
+                elif line.startswith("processor"):
+                    logical += 1
+                    pid = cid = None
+                elif line.startswith("physical id"):
+                    pid = line.split(":", 1)[1].strip()
+                    sockets.add(pid)
+                elif line.startswith("core id"):
+                    cid = line.split(":", 1)[1].strip()
+                    phys.add((pid, cid))
     except OSError:
         pass
     isa = [k for k in ("avx2", "avx512f", "avx512_bf16", "avx512_fp16", "amx_bf16", "amx_tile") if k in flags]
-    return model, isa
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = None
+    topo = {"sockets": len(sockets) or None, "physical_cores": len(phys) or None, "logical_cpus": logical or None,
+            "cpus_allowed": allowed}
+    return model, isa, topo
 
 
 def cpu_baseline(T, dtype, budget_s=12.0, min_calls=5):
@@ -311,9 +329,9 @@ def cpu_baseline(T, dtype, budget_s=12.0, min_calls=5):
         spent += sum(times)
         calls += len(times)
         flops += 2.0 * T * n * kin
-    model, isa = host_cpu()
+    model, isa, topo = host_cpu()
     return {"value": flops / med_secs / 1e12, "unit": "TFLOP/s", "cores": cores, "kind": "port",
-            "cpu_model": model, "cpu_isa": isa, "tokens": T, "layer_ms": med_secs * 1e3,
+            "cpu_model": model, "cpu_isa": isa, "cpu_topology": topo, "tokens": T, "layer_ms": med_secs * 1e3,
             "sample": f"{calls} apply() calls over qkv/o/gate_up/down of one Llama-3-8B decoder layer at T={T} "
                       f"(at least {min_calls} per linear, median call time of each; {spent:.1f} s of CPU work, "
                       f"{cores} threads), torch-CPU restatement of the reference's generic_dequantize_gemm"}
@@ -439,6 +457,32 @@ def layer_chain(stack, T, device, dtype, cfg=LLAMA3_8B, reps=5):
                                                                  "down_proj"], "launch": "hipgraph"}
 
 
+def mid_batches(stack, device, dtype, tokens=(128, 256), reps=32):
+    """Mid-size batches (continuous-batching decode, chunked prefill): every linear of a decoder layer at these token
+    counts, one launch timed as the dominant kernel is (HIP events around a graph replay of back-to-back launches over
+    the layers' distinct weights), its fraction of the binding roofline, and the four-linear sum."""
+    from vllm_pq_amd import ops
+    out = {}
+    for T in tokens:
+        inputs = make_inputs(stack[0], T, device, dtype)
+        rec, total_us, total_peak_us = {}, 0.0, 0.0
+        for (name, n, kin, p) in shapes_of(stack[0]):
+            t = time_dominant_kernel(stack, inputs, name, max(reps, len(stack)))
+            flops, byts = 2.0 * T * n * kin, algorithmic_bytes(T, n, kin, p)
+            peak_s = max(flops / (MFMA_PEAK_TFLOPS * 1e12), byts / (HBM_PEAK_GBPS * 1e9))
+            parts = stack[0][name].codebooks.output_partition_sizes
+            rec[name] = {"launch_us": t * 1e6, "frac": peak_s / t,
+                         "bound": "mfma" if flops / (MFMA_PEAK_TFLOPS * 1e12) >= byts / (HBM_PEAK_GBPS * 1e9) else "hbm",
+                         "kernel": ops.gemm_kernel_name(T, n, kin // SUB_DIM, NUM_CODEBOOKS, K_ENTRIES, SUB_DIM, 1, dtype, parts,
+                                                        packed=getattr(stack[0][name], "pq_packed_codes", None) is not None)}
+            total_us += t * 1e6
+            total_peak_us += peak_s * 1e6
+        rec["four_linears_us"] = total_us
+        rec["four_linears_frac"] = total_peak_us / total_us
+        out[f"T{T}"] = rec
+    return out
+
+
 def mfma_ceiling(device, dtype, seconds=1.5):
     """What a bare MFMA loop reaches on THIS device with operands drawn like the benchmark's (normal values rounded
     to the act dtype, in registers, no memory traffic; tools/pq_probe.hip): the chip lowers its clock under MFMA load
@@ -478,18 +522,23 @@ def mfma_ceiling(device, dtype, seconds=1.5):
 
 
 def profiled_traffic(key):
-    """HBM bytes per launch of a kernel as measured by the committed rocprofv3 counter passes
-    (profiles/traffic_r*.json, newest round first); None when that launch was not profiled."""
+    """(HBM bytes per launch of a kernel, where the number comes from): measured by the committed rocprofv3 counter
+    passes (profiles/traffic_r*.json, newest round first) -- not in this run, PMC counters need the profiler --;
+    (None, None) when that launch was not profiled."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
         try:
             with open(path) as f:
-                rec = json.load(f).get(key)
+                doc = json.load(f)
+            rec = doc.get(key)
             if rec:
-                return rec["hbm_bytes"]
+                return rec["hbm_bytes"], {"file": os.path.relpath(path, ROOT), "commit": doc.get("commit", "unrecorded"),
+                                          "box": doc.get("box", "unrecorded"),
+                                          "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh "
+                                                 "(committed; not measured in this run)"}
         except (OSError, ValueError, KeyError):
             pass
-    return None
+    return None, None
 
 
 def split_times(stack, inputs, T, steps, warmup, device, dtype, dist_on, use_graph):
@@ -610,6 +659,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-neighbours", action="store_true", help="skip the element-wise kernels' measurement")
+    ap.add_argument("--no-mid", action="store_true", help="skip the mid-size batches (128 and 256 tokens per linear)")
     ap.add_argument("--dry-ranks", action="store_true",
                     help="every rank prints its RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as one JSON line and exits "
                          "without touching a GPU (exercises the rank launcher)")
@@ -673,7 +723,7 @@ def main():
     else:
         roof = {"bound": "hbm", "achieved": k_bytes / t_k / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["traffic"] = profiled_traffic(f"{dom}@T{T}:{kname}") if world == 1 else None
+    roof["traffic"], roof["traffic_source"] = profiled_traffic(f"{dom}@T{T}:{kname}") if world == 1 else (None, None)
     roof.update({"kernel": f"{kname}:{dom}", "launch_us": t_k * 1e6, "launches_timed": reps,
                  "algorithmic_bytes": k_bytes, "algorithmic_flops": k_flops})
     if roof["bound"] == "mfma" and rank == 0:
@@ -697,7 +747,10 @@ def main():
                                "frac": kb / t_kd / 1e9 / HBM_PEAK_GBPS,
                                "traffic": profiled_traffic(f"{dom}@T{Td}:" + ops.gemm_kernel_name(
                                    Td, n_d, kin_d // SUB_DIM, 1, K_ENTRIES, SUB_DIM, 1, dtype, dom_parts,
-                                   packed=dom_packed)) if world == 1 else None,
+                                   packed=dom_packed))[0] if world == 1 else None,
+                               "traffic_source": profiled_traffic(f"{dom}@T{Td}:" + ops.gemm_kernel_name(
+                                   Td, n_d, kin_d // SUB_DIM, 1, K_ENTRIES, SUB_DIM, 1, dtype, dom_parts,
+                                   packed=dom_packed))[1] if world == 1 else None,
                                "kernel": ops.gemm_kernel_name(Td, n_d, kin_d // SUB_DIM, 1, K_ENTRIES, SUB_DIM, 1, dtype,
                                                               dom_parts, packed=dom_packed) + ":" + dom,
                                "launch_us": t_kd * 1e6}}
@@ -714,6 +767,20 @@ def main():
         if not args.no_decode and args.decode_tokens != T:
             chain[f"T{args.decode_tokens}"] = layer_chain(stack, args.decode_tokens, device, dtype)
 
+    mid = None
+    if world == 1 and not args.no_mid:
+        mid = mid_batches(stack, device, dtype)
+
+    # the peer-buffer all-reduce's status word after everything timed: a wait that gave up poisons its output and stays on record
+    ar_status = None
+    if world > 1 and parallel_state._XGMI_AR is not None:
+        torch.cuda.synchronize()
+        try:
+            parallel_state._XGMI_AR.check()
+            ar_status = "ok"
+        except RuntimeError as e:
+            ar_status = f"FAILED: {e}"
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(T, dtype)
@@ -729,11 +796,15 @@ def main():
             "config": {"workload": "Llama-3-8B PQ linears (qkv/o/gate_up/down x %d layers), K=256, sub-dim=8, M=1"
                                    % len(stack),
                        "tokens_per_step": T, "parallelism": f"tp{world}", "launch": main_m["launch"],
-                       "apply_calls_per_step": 4 * len(stack)},
+                       "apply_calls_per_step": 4 * len(stack),
+                       "tokens_per_s_covers": "the PQ linear layers only (no attention, norms, sampling): tokens of a "
+                                              "step / step time of the 128 apply() calls"},
             "hbm_gbps": main_m["gbps"], "tokens_per_s": main_m["tokens_per_s"],
             "roofline": roof, "cpu_baseline": cpu, "decode": decode, "neighbours": neighbours,
-            "layer_chain": chain,
+            "layer_chain": chain, "mid_batches": mid,
         }
+        if ar_status is not None:
+            line["pq_ar_status"] = ar_status
         if main_m["split"]:
             line.update(main_m["split"])
         print(json.dumps(line), flush=True)

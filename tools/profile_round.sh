@@ -1,8 +1,9 @@
 #!/bin/bash
 # Round profile on the GPU box: bench line, rocprofv3 kernel trace + stats, three separate PMC passes.
-# Usage (from the repo root, on the GPU box):  bash tools/profile_round.sh <tag>
+# Usage (from the repo root, on the GPU box):  bash tools/profile_round.sh <tag> [commit]
 set -e -o pipefail
 TAG=${1:-r01}
+export PQ_COMMIT=${2:-${PQ_COMMIT:-}}     # the commit under test (the GPU box has no .git): recorded in traffic.json
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"

@@ -9,6 +9,9 @@ import collections
 import csv
 import glob
 import json
+import os
+import socket
+import subprocess
 import sys
 
 
@@ -28,7 +31,22 @@ def pick(meds, mark, grid):
 
 def main():
     fetch, write, tag = medians(sys.argv[1], "FETCH_SIZE"), medians(sys.argv[2], "WRITE_SIZE"), sys.argv[3]
-    out = {"note": f"HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction for "
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:   # the commit the counters belong to (no .git on the GPU box: the caller passes it in PQ_COMMIT)
+        commit = os.environ.get("PQ_COMMIT") or subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"],
+                                                                capture_output=True, text=True, timeout=10).stdout.strip()
+    except Exception:
+        commit = ""
+    gpu = ""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pr = torch.cuda.get_device_properties(0)
+            gpu = f"{pr.name} ({pr.gcnArchName}, {pr.multi_processor_count} CUs)"
+    except Exception:
+        pass
+    out = {"commit": commit or "unknown", "box": {"host": socket.gethostname(), "gpu": gpu},
+           "note": f"HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction for "
                    f"16-B-per-lane streams, + WRITE_SIZE), round {tag}, medians over the launches of the kernel "
                    f"(the dominant layer's); see profiles/README.md"}
     # gate_up_proj at 4096 tokens: the 512 x 128 tiled kernel (256 persistent blocks); at 16 tokens: the decode
