@@ -29,5 +29,6 @@ def test_two_ranks_on_one_gpu():
         with open(path) as f:
             res = json.load(f)
         assert res["ok"], res.get("error")
-        assert res["checks"] == ["known answer", "sizes and dtypes", "graph replay", "fused add + norm",
+        assert res["checks"] == ["known answer", "sizes and dtypes", "graph replay",
+                                 "row-parallel layer with fused sum + add + norm", "fused add + norm",
                                  "timeout poisons the output"]

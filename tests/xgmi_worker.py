@@ -121,6 +121,34 @@ def main():
             assert bad.numel() == 0, (f"normed {T}x{H} {dt}: {bad.shape[0]} differ, first at {bad[0].tolist()}: "
                                       f"{xw[tuple(bad[0].tolist())].item()} vs {summed[tuple(bad[0].tolist())].item()}; "
                                       f"rows {sorted(set(bad[:, 0].tolist()))[:8]} cols {bad[:8, 1].tolist()}")
+        # the same through the row-parallel layer: o_proj -> sum over ranks + residual add + RMSNorm in one call, against
+        # forward() followed by the norm kernel
+        from vllm_pq_amd import PQConfig
+        from vllm_pq_amd.host.linear import RowParallelLinear
+        torch.manual_seed(4242)
+        row = RowParallelLinear(1024 * world, 2048, bias=True, params_dtype=torch.bfloat16, quant_config=PQConfig(8, 8, 1, 1))
+        row.codes.data = torch.randint(-128, 128, row.codes.shape, dtype=torch.int8)
+        row.codebooks.data = torch.randn(row.codebooks.shape).to(torch.bfloat16)
+        row.scales.data = (torch.rand(row.scales.shape) + 0.5).to(torch.bfloat16)
+        row.bias.data = torch.randn(row.bias.shape).to(torch.bfloat16)
+        row.to(dev)
+        row.quant_method.process_weights_after_loading(row)
+        for T in (1, 16, 40):
+            g = torch.Generator().manual_seed(77 + T + rank)
+            xr = torch.randn(T, 1024, generator=g).to(torch.bfloat16).to(dev)
+            g2 = torch.Generator().manual_seed(7)
+            res0 = torch.randn(T, 2048, generator=g2).to(torch.bfloat16).to(dev)
+            w = (torch.rand(2048, generator=g2) + 0.5).to(torch.bfloat16).to(dev)
+            res_f = res0.clone()
+            xw = row.forward_add_norm(xr, res_f, w, 1e-5)
+            y, _ = row(xr)
+            res_u = res0.clone()
+            ops.fused_add_rms_norm(y, res_u, w, 1e-5)
+            torch.cuda.synchronize()
+            assert torch.equal(res_f.view(torch.int16), res_u.view(torch.int16)), f"row layer residual T={T}"
+            assert torch.equal(xw.view(torch.int16), y.view(torch.int16)), f"row layer normed T={T}"
+        res["checks"].append("row-parallel layer with fused sum + add + norm")
+
         # not taken (too large for one shot / rows not a multiple of 8): the two steps run, same interface
         big = torch.randn(256, 4096).to(torch.bfloat16).to(dev)
         assert not ar.add_norm_supported(big, torch.empty_like(big))

@@ -66,7 +66,7 @@ static float run(const Shape &sh, int T, int nf, int rounds, const char *label, 
     dim3 grid; size_t lds;
     WideParams p0 = make_params(sh, T, nf, rounds, x, pk[0], cb, sc, nullptr, y, &grid, &lds);
     const int nblk = grid.x;
-    CK(hipMalloc(&st, (size_t)nblk * 40 * 8)); CK(hipMemset(st, 0, (size_t)nblk * 40 * 8));
+    CK(hipMalloc(&st, (size_t)nblk * 56 * 8)); CK(hipMemset(st, 0, (size_t)nblk * 56 * 8));
     auto kern = gemm_wide_kernel<bf16_t, STAMPS, ABL>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     auto launch = [&](int i) {
@@ -91,15 +91,15 @@ static float run(const Shape &sh, int T, int nf, int rounds, const char *label, 
     printf("%-10s T=%4d %-22s nf=%d rounds=%2d blocks=%4d  %7.2f us/launch  %6.1f TFLOP/s  frac %.3f\n", sh.name, T, label, nf, rounds,
            nblk, us, flops / us * 1e-6, flops / us * 1e-6 / 2500.0);
     if (STAMPS && stamps_out) {
-        std::vector<unsigned long long> hs((size_t)nblk * 40);
-        CK(hipMemcpy(hs.data(), st, (size_t)nblk * 40 * 8, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> hs((size_t)nblk * 56);
+        CK(hipMemcpy(hs.data(), st, (size_t)nblk * 56 * 8, hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull;
-        for (int b = 0; b < nblk; ++b) if (hs[(size_t)b * 40]) t0 = std::min(t0, hs[(size_t)b * 40]);
+        for (int b = 0; b < nblk; ++b) if (hs[(size_t)b * 56]) t0 = std::min(t0, hs[(size_t)b * 56]);
         const char *names[12] = {"block start", "tile found", "entries + x requested", "first x fragment in regs", "x in registers",
                                  "barrier", "image stored + barrier", "first gathers issued", "first round's units done", "all rounds done", "", "stores retired"};
         for (int k : {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11}) {
             std::vector<double> v;
-            for (int b = 0; b < nblk; ++b) if (hs[(size_t)b * 40]) v.push_back((hs[(size_t)b * 40 + k] - t0) / 100.0);
+            for (int b = 0; b < nblk; ++b) if (hs[(size_t)b * 56]) v.push_back((hs[(size_t)b * 56 + k] - t0) / 100.0);
             std::sort(v.begin(), v.end());
             printf("     %-26s min %6.2f  med %6.2f  max %6.2f us (wave 0)\n", names[k], v[0], v[v.size() / 2], v.back());
         }
@@ -108,11 +108,23 @@ static float run(const Shape &sh, int T, int nf, int rounds, const char *label, 
             for (int k = 1; k < 7; ++k) {
                 std::vector<double> v;
                 for (int b = 0; b < nblk; ++b)
-                    if (hs[(size_t)b * 40] && hs[(size_t)b * 40 + w * 20 + 12 + k] && hs[(size_t)b * 40 + w * 20 + 12])
-                        v.push_back((double)(hs[(size_t)b * 40 + w * 20 + 12 + k] - hs[(size_t)b * 40 + w * 20 + 12]) / 100.0);
+                    if (hs[(size_t)b * 56] && hs[(size_t)b * 56 + w * 28 + 12 + k] && hs[(size_t)b * 56 + w * 28 + 12])
+                        v.push_back((double)(hs[(size_t)b * 56 + w * 28 + 12 + k] - hs[(size_t)b * 56 + w * 28 + 12]) / 100.0);
                 if (v.empty()) continue;
                 std::sort(v.begin(), v.end());
                 printf("       second round, wave %d: %-22s +%5.2f (min %5.2f max %5.2f) us after the round's start\n", w ? 7 : 0, rn[k], v[v.size() / 2], v[0], v.back());
+            }
+        const char *un[8] = {"unit starts", "next piece requested", "second-half gathers issued", "piece waited for, codes read issued", "first-half MFMAs issued",
+                             "second-half gathers landed", "next first-half gathers issued", "second-half MFMAs issued, tiles stored"};
+        for (int w = 0; w < 2; ++w)
+            for (int k = 1; k < 8; ++k) {
+                std::vector<double> v;
+                for (int b = 0; b < nblk; ++b)
+                    if (hs[(size_t)b * 56] && hs[(size_t)b * 56 + w * 28 + 20 + k] && hs[(size_t)b * 56 + w * 28 + 20])
+                        v.push_back((double)(hs[(size_t)b * 56 + w * 28 + 20 + k] - hs[(size_t)b * 56 + w * 28 + 20]));
+                if (v.empty()) continue;
+                std::sort(v.begin(), v.end());
+                printf("         second unit, wave %d: %-40s +%6.0f shader cycles (min %6.0f max %6.0f)\n", w ? 7 : 0, un[k], v[v.size() / 2], v[0], v.back());
             }
     }
     for (auto q : pk) CK(hipFree(q));

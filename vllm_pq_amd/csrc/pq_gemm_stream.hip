@@ -56,6 +56,13 @@ static bool stream_light_format(const GemmArgs &a) { return a.d == 8 && a.M == 1
 // sum) plus 1.9 us per activation sub-load of a wave: with more than 16 tokens the round trips of the
 // activation loads to L2, only one sub-chunk ahead, set the pace, not the code stream or the MFMAs.  A
 // sub-load is 32 registers, i.e. 8 / TF k-steps of the chunk's KS.
+// What a K split over blocks adds to a launch: 2 us for the count and the last block's second pass, and the fp32
+// partial sums written and read again past the L2 (about 2.5 TB/s): negligible at 16 tokens, 1.7 us for 64 tokens
+// of a 4096-row layer split in two.
+static double ksplit_us(const GemmArgs &a, int ksplit) {
+    return ksplit > 1 ? 2.0 + 2.0 * ksplit * (double)a.T * a.N * 4.0 / 2.5e6 : 0.0;
+}
+
 static double stream_model_us(const GemmArgs &a, int nf, int tf, int ksplit) {
     const int cg = chunk_groups(a.code_bytes, a.M);
     const int ks = (cg / 4) * a.d / 8;                               // k-steps per chunk
@@ -67,8 +74,9 @@ static double stream_model_us(const GemmArgs &a, int nf, int tf, int ksplit) {
     const double tall = nf > 4 ? 1.3 * (nf - 4) : 0.0;   // gathers of the fragments beyond four, per chunk
     const double fixed = stream_light_format(a) ? 4.0 : 7.0;   // measured: 3 us more for d < 8, two-byte codes, M = 2
     // (from 16 tokens on the packed layout's activation loads run with the lanes along the rows: 1.55 us per sub-load)
-    const double sub_us = a.packed && a.T >= 16 ? 1.55 : 1.9;
-    return rounds * (fixed + (ksplit > 1 ? 2.0 : 0.0) + per_wave * ((ks / subk) * sub_us + tall));   // + 2 us: partial sums, count, re-read
+    // (64-token blocks: 1.3 us, measured on down_proj and o_proj at 256 tokens -- a sub-load of theirs is two k-steps)
+    const double sub_us = a.packed && a.T >= 16 ? (tf == 4 ? 1.3 : 1.55) : 1.9;
+    return rounds * (fixed + ksplit_us(a, ksplit) + per_wave * ((ks / subk) * sub_us + tall));
 }
 
 // The same for blocks of one token fragment (TF = 1) and NF weight fragments: 5.3 us fixed (3.8 when a short K
@@ -88,7 +96,8 @@ static double stream_tall_model_us(const GemmArgs &a, int nf, int ksplit) {
     const double ld = a.packed && a.T >= 16 ? 0.85 : 1.0;   // activation loads with the lanes along the rows
     const double chunks_us = scale * (1.0 * ld + 0.5 * nf) + (per_wave - 1.0) * (1.55 * ld * nsub + scale * 0.2 * nf);
     const double busy = nchunks / 8.0 < 1.0 ? nchunks / 8.0 : 1.0;   // waves of a block that have a chunk at all
-    return rounds * (3.3 + 2.0 * busy + (ksplit > 1 ? 2.0 : 0.0) + chunks_us);
+    // (a second pass over the chip costs more than the first: measured 46.6 against a modelled 41.5 us, down_proj at 256 tokens)
+    return rounds * (rounds > 1.0 ? 1.1 : 1.0) * (3.3 + 2.0 * busy + ksplit_us(a, ksplit) + chunks_us);
 }
 
 // ---- K split over blocks ---------------------------------------------------------------------------

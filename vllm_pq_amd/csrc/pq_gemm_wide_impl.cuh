@@ -76,7 +76,7 @@ __device__ __forceinline__ uint32_t wd_gload4(uint32_t voff, const void *sbase) 
 }
 
 // STAMPS (diagnostic builds only): wave 0 and the last wave keep wall-clock stamps of the phases and store them at the
-// end to `bias` (40 x u64 per block).  ABL (diagnostic builds only): bit 0 leaves the MFMAs out, bit 1 the gathers.
+// end to `bias` (56 x u64 per block).  ABL (diagnostic builds only): bit 0 leaves the MFMAs out, bit 1 the gathers.
 template <typename AT, bool STAMPS = false, int ABL = 0>
 __global__ __launch_bounds__(WD_WAVES * 64) void gemm_wide_kernel(const WideParams p) {
     typedef typename Act<AT>::vec8 vec8;
@@ -93,15 +93,16 @@ __global__ __launch_bounds__(WD_WAVES * 64) void gemm_wide_kernel(const WidePara
     if (row_tile >= p.n_tiles) return;                    // the grid is rounded up to whole groups of 8 row tiles
     const int tok0 = (in_xcd % p.tgroups) * WD_TOKENS;
     const int T = p.T;
-    unsigned long long st[12], sr[8];   // sr: inside the block's second round (the first of a one-round block)
+    unsigned long long st[12], sr[8], su[8];   // sr: inside the block's second round (the first of a one-round block); su: inside that round's second unit
     if constexpr (STAMPS) {
         bias = nullptr;
 #pragma unroll
         for (int k = 0; k < 12; ++k) st[k] = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sr[k] = 0;
+        for (int k = 0; k < 8; ++k) sr[k] = su[k] = 0;
         st[0] = __builtin_amdgcn_s_memrealtime();
     }
+#define WD_USTAMP(k) if constexpr (STAMPS) { if (r == (rounds > 1 ? 1 : 0) && i == (nf > 1 ? 1 : 0)) { asm volatile("" ::: "memory"); su[k] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } }
 #define WD_RSTAMP(k) if constexpr (STAMPS) { if (r == (rounds > 1 ? 1 : 0)) { asm volatile("" ::: "memory"); sr[k] = __builtin_amdgcn_s_memrealtime(); asm volatile("" ::: "memory"); } }
 #define WD_STAMP(k) if constexpr (STAMPS) { asm volatile("" ::: "memory"); st[k] = __builtin_amdgcn_s_memrealtime(); asm volatile("" ::: "memory"); }
 
@@ -288,9 +289,12 @@ __global__ __launch_bounds__(WD_WAVES * 64) void gemm_wide_kernel(const WidePara
 #pragma nounroll
             for (int i = 0; i < nf; ++i) {
                 if (i == 1) { WD_RSTAMP(1) }   // first unit done
+                WD_USTAMP(0)
                 dma_unit();             // unit u + ahead into the slot this unit's piece has left
                 f32x4 accA{0.f, 0.f, 0.f, 0.f}, accB{0.f, 0.f, 0.f, 0.f};
+                WD_USTAMP(1)
                 WD_GHI
+                WD_USTAMP(2)
                 // The next unit's piece: behind it the ahead - 1 younger requests.  The counter also counts the stores
                 // of a round's epilogue, in order with the loads: so that the first unit of a round does not wait for
                 // stores issued a moment ago, the last unit of the round before it has waited for one piece more (this
@@ -298,8 +302,10 @@ __global__ __launch_bounds__(WD_WAVES * 64) void gemm_wide_kernel(const WidePara
                 dc_wait_vm(i == nf - 1 ? ahead - 2 : i == 0 && r > 0 ? 47 : ahead - 1);
                 const uint32_t nslot = cslot == ring_last ? ring0 : cslot + 1024u;
                 u32x4 cwn = dc_lds_read16(nslot + lane16);
+                WD_USTAMP(3)
                 // behind a0[j]: 7 - j of its set, 8 of the other set, the read above (and the two stores of the unit before)
                 WD_MW(0, 0, 15) WD_MW(1, 1, 15) WD_MW(2, 2, 14) WD_MW(3, 3, 13) WD_MW(4, 4, 12) WD_MW(5, 5, 11) WD_MW(6, 6, 10) WD_MW(7, 7, 9)
+                WD_USTAMP(4)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 dc_landed(cwn);
 #define WD_L1(j) dc_landed(a1[j]);
@@ -307,10 +313,13 @@ __global__ __launch_bounds__(WD_WAVES * 64) void gemm_wide_kernel(const WidePara
 #undef WD_L1
                 cw = cwn;
                 cslot = nslot;
+                WD_USTAMP(5)
                 WD_GLO                   // first half of the next unit (of this one again after the last: never used)
+                WD_USTAMP(6)
                 WD_MN(0, 8) WD_MN(1, 9) WD_MN(2, 10) WD_MN(3, 11) WD_MN(4, 12) WD_MN(5, 13) WD_MN(6, 14) WD_MN(7, 15)
                 *reinterpret_cast<f32x4 *>(acc_tiles + ((size_t)(i * WD_WT) * 64 + lane) * 16) = accA;
                 *reinterpret_cast<f32x4 *>(acc_tiles + ((size_t)(i * WD_WT + 1) * 64 + lane) * 16) = accB;
+                WD_USTAMP(7)
             }
             // the gathers issued behind the round's last unit: landed before any branch
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -406,15 +415,18 @@ __global__ __launch_bounds__(WD_WAVES * 64) void gemm_wide_kernel(const WidePara
         st[11] = __builtin_amdgcn_s_memrealtime();   // stores retired
         if (lane == 0 && (wave == 0 || wave == WD_WAVES - 1)) {
             unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<uint16_t *>(p.bias)) +
-                                    (size_t)blockIdx.x * 40 + (wave == 0 ? 0 : 20);
+                                    (size_t)blockIdx.x * 56 + (wave == 0 ? 0 : 28);
 #pragma unroll
             for (int k = 0; k < 12; ++k) o[k] = st[k];
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[12 + k] = sr[k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[20 + k] = su[k];
         }
     }
 #undef WD_STAMP
 #undef WD_RSTAMP
+#undef WD_USTAMP
 }
 
 }  // namespace pq

@@ -308,3 +308,21 @@ class RowParallelLinear(LinearBase):
         if self.reduce_results and self.tp_size > 1:
             out = tensor_model_parallel_all_reduce(out, in_place=True)     # apply()'s output is this call's own
         return self._result(out)
+
+    def forward_add_norm(self, input_: torch.Tensor, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float):
+        """forward() followed by the decoder block's `RMSNorm.forward(out, residual)` (the pair a Llama layer runs
+        behind o_proj and down_proj, vllm/model_executor/models/llama.py:272-284): `residual` becomes out + residual in
+        place, the normalised tensor is returned.  With several ranks the sum over ranks, the add and the norm are one
+        launch where the peer-buffer all-reduce takes the batch (decode sizes), the collective followed by the norm
+        kernel otherwise -- the same values either way.  With one rank the add + norm rides on the GEMMs either side of
+        it where the method fuses that (PQLinearMethod.apply_add_norm); this entry is for tp_size > 1 and plain layers."""
+        from . import parallel_state
+        from .. import ops
+        if not (self.reduce_results and not self.skip_bias_add):
+            raise ValueError("forward_add_norm: a layer that reduces its results and adds its bias itself")
+        x = input_ if self.input_is_parallel else split_tensor_along_last_dim(input_, self.tp_size)[self.tp_rank].contiguous()
+        out = self.quant_method.apply(self, x, bias=None if self.tp_rank > 0 else self.bias)
+        if self.tp_size > 1:
+            return parallel_state.tensor_model_parallel_all_reduce_add_norm(out, residual, norm_weight, eps)
+        ops.fused_add_rms_norm(out, residual, norm_weight, eps)
+        return out
