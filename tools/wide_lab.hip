@@ -38,8 +38,9 @@ static WideParams make_params(const Shape &sh, int T, int nf, int rounds, void *
     return p;
 }
 
-template <bool STAMPS, int ABL>
-static float run(const Shape &sh, int T, int nf, int rounds, const char *label, bool stamps_out) {
+template <bool STAMPS, int ABL, int NF>
+static float run_nf(const Shape &sh, int T, int rounds, const char *label, bool stamps_out) {
+    const int nf = NF;
     int N = 0;
     for (int p = 0; p < sh.nparts; ++p) N += sh.parts[p];
     const int nchunks = sh.Kin / 512;
@@ -67,7 +68,7 @@ static float run(const Shape &sh, int T, int nf, int rounds, const char *label, 
     WideParams p0 = make_params(sh, T, nf, rounds, x, pk[0], cb, sc, nullptr, y, &grid, &lds);
     const int nblk = grid.x;
     CK(hipMalloc(&st, (size_t)nblk * 56 * 8)); CK(hipMemset(st, 0, (size_t)nblk * 56 * 8));
-    auto kern = gemm_wide_kernel<bf16_t, STAMPS, ABL>;
+    auto kern = gemm_wide_kernel<bf16_t, NF, STAMPS, ABL>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     auto launch = [&](int i) {
         WideParams p = p0;
@@ -130,6 +131,16 @@ static float run(const Shape &sh, int T, int nf, int rounds, const char *label, 
     for (auto q : pk) CK(hipFree(q));
     CK(hipFree(x)); CK(hipFree(cb)); CK(hipFree(sc)); CK(hipFree(y)); CK(hipFree(st));
     return us;
+}
+
+template <bool STAMPS, int ABL>
+static float run(const Shape &sh, int T, int nf, int rounds, const char *label, bool stamps_out) {
+    switch (nf) {
+    case 1: return run_nf<STAMPS, ABL, 1>(sh, T, rounds, label, stamps_out);
+    case 2: return run_nf<STAMPS, ABL, 2>(sh, T, rounds, label, stamps_out);
+    case 3: return run_nf<STAMPS, ABL, 3>(sh, T, rounds, label, stamps_out);
+    default: return run_nf<STAMPS, ABL, 4>(sh, T, rounds, label, stamps_out);
+    }
 }
 
 static void choose(const Shape &sh, int T, int *nf, int *rounds) {

@@ -57,8 +57,8 @@ WideGeom choose_wide_geom(const GemmArgs &a, double *model_us) {
     return g;
 }
 
-template <typename AT>
-static hipError_t launch_wide_at(const GemmArgs &a, const WideGeom &g, hipStream_t stream) {
+template <typename AT, int NF>
+static hipError_t launch_wide_nf(const GemmArgs &a, const WideGeom &g, hipStream_t stream) {
     WideParams p;
     p.x = static_cast<const unsigned char *>(a.x);
     p.codes = static_cast<const unsigned char *>(a.codes);
@@ -87,8 +87,8 @@ static hipError_t launch_wide_at(const GemmArgs &a, const WideGeom &g, hipStream
     // whole groups of 8 row tiles (one per XCD), each with its token groups back to back on that XCD
     const dim3 grid((unsigned)((p.n_tiles + 7) / 8 * 8 * p.tgroups));
     const size_t lds = wd_lds_bytes(p.img_bytes, g.nf, frags_blk);
-    auto kern = gemm_wide_kernel<AT>;
-    static std::atomic<bool> attr_set[64];   // per device and act dtype (this function is a template): more than 64 KiB of LDS
+    auto kern = gemm_wide_kernel<AT, NF>;
+    static std::atomic<bool> attr_set[64];   // per device, act dtype and NF (this function is a template): more than 64 KiB of LDS
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
@@ -101,11 +101,21 @@ static hipError_t launch_wide_at(const GemmArgs &a, const WideGeom &g, hipStream
     return hipGetLastError();
 }
 
+template <typename AT>
+static hipError_t launch_wide_at(const GemmArgs &a, const WideGeom &g, hipStream_t stream) {
+    switch (g.nf) {
+    case 1: return launch_wide_nf<AT, 1>(a, g, stream);
+    case 2: return launch_wide_nf<AT, 2>(a, g, stream);
+    case 3: return launch_wide_nf<AT, 3>(a, g, stream);
+    default: return launch_wide_nf<AT, 4>(a, g, stream);
+    }
+}
+
 hipError_t launch_gemm_wide(const GemmArgs &a, hipStream_t stream) {
     if (a.N == 0 || a.T == 0) return hipSuccess;
     if (!gemm_wide_supported(a)) return hipErrorInvalidValue;
     const WideGeom g = choose_wide_geom(a, nullptr);
-    if (g.nf == 0) return hipErrorInvalidValue;
+    if (g.nf < 1 || g.nf > WD_MAX_NF) return hipErrorInvalidValue;
     return a.dtype == PQ_DTYPE_BF16 ? launch_wide_at<bf16_t>(a, g, stream) : launch_wide_at<fp16_t>(a, g, stream);
 }
 

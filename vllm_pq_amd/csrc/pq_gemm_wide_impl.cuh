@@ -75,9 +75,18 @@ __device__ __forceinline__ uint32_t wd_gload4(uint32_t voff, const void *sbase) 
     return v;
 }
 
+template <int OFF>
+__device__ __forceinline__ uint32_t wd_lds_read4_at(uint32_t addr) {
+    uint32_t v;
+    asm volatile("; PQX %0\n\tds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
 // STAMPS (diagnostic builds only): wave 0 and the last wave keep wall-clock stamps of the phases and store them at the
 // end to `bias` (56 x u64 per block).  ABL (diagnostic builds only): bit 0 leaves the MFMAs out, bit 1 the gathers.
-template <typename AT, bool STAMPS = false, int ABL = 0>
+// NF: fragments per wave and round, a compile-time value so that the depth of the code ring -- and with it every counted
+// wait of the unit loop -- is an immediate (a computed jump into a table of waits costs a unit about 80 cycles).
+template <typename AT, int NF, bool STAMPS = false, int ABL = 0>
 __global__ __launch_bounds__(WD_WAVES * 64) void gemm_wide_kernel(const WideParams p) {
     typedef typename Act<AT>::vec8 vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -108,7 +117,8 @@ __global__ __launch_bounds__(WD_WAVES * 64) void gemm_wide_kernel(const WidePara
 
     const int WK = 1 << p.wk_log2, WR = WD_WAVES >> p.wk_log2;
     const int wk = wave & (WK - 1), wr = wave >> p.wk_log2;
-    const int nf = p.nf, rounds = p.rounds;
+    constexpr int nf = NF;
+    const int rounds = p.rounds;
     const bool has_chunk = wk < p.nchunks;                // a wave beyond the last chunk contributes zeros
 
     // ---- the block's tile
@@ -193,18 +203,23 @@ __global__ __launch_bounds__(WD_WAVES * 64) void gemm_wide_kernel(const WidePara
     // counts, no branch around a load), fragments past the tile's last repeat that one and are never stored.
     const int UT = rounds * nf;
     const uint32_t ring0 = lds0 + p.img_bytes + (uint32_t)wave * p.wave_bytes;
-    const int ahead = p.ring;                             // a unit's piece is requested `ahead` units before its use
+    constexpr int ahead = wd_ring(NF);                    // a unit's piece is requested `ahead` units before its use
     const uint32_t ring_last = ring0 + (uint32_t)(ahead - 1) * 1024u;
     const size_t frag_bytes = (size_t)p.nchunks * 1024;
     const unsigned char *code_base = p.codes + ((size_t)(loc.row0 >> 4) * p.nchunks + (has_chunk ? wk : 0)) * 1024;
-    int du = 0, dr = 0, di = 0;
+    // the next piece to request: unit `du`, whose fragment is `dfr` of the tile, at byte offset `doff` from code_base (a
+    // tile's pieces span at most 64 fragments x 8 KiB); requests past the last unit repeat it, fragments past the tile's
+    // last repeat that one
+    int du = 0, di = 0;
+    uint32_t doff = (uint32_t)(wr * nf) * (uint32_t)frag_bytes;
+    const uint32_t doff_max = (uint32_t)(nfr - 1) * (uint32_t)frag_bytes;
+    const uint32_t dstep_round = (uint32_t)((WR - 1) * nf + 1) * (uint32_t)frag_bytes;   // from a round's last fragment to the next round's first
     uint32_t dslot = ring0;
     auto dma_unit = [&]() {
-        const int fr = (dr * WR + wr) * nf + di;
-        dc_dma16(dslot, lane16, code_base + (size_t)(fr < nfr ? fr : nfr - 1) * frag_bytes);
+        dc_dma16(dslot, lane16, code_base + (doff < doff_max ? doff : doff_max));
         if (du + 1 < UT) {
             ++du;
-            if (++di == nf) { di = 0; ++dr; }
+            if (++di == nf) { di = 0; doff += dstep_round; } else doff += (uint32_t)frag_bytes;
         }
         dslot = dslot == ring_last ? ring0 : dslot + 1024u;
     };
@@ -254,31 +269,44 @@ __global__ __launch_bounds__(WD_WAVES * 64) void gemm_wide_kernel(const WidePara
 
     const uint32_t img_lane = lds0 + (uint32_t)(lane & 15) * 16u;   // this lane's copy of entry 0
     const uint32_t sel0 = 0x0c0c0400u, sel1 = 0x0c0c0500u, sel2 = 0x0c0c0600u, sel3 = 0x0c0c0700u;
-    // Units are software-pipelined over two sets of 8 gathered weight fragments as in the decode kernel: while the MFMAs
-    // of one half of a unit's k-steps run (two per gathered fragment), the gathers of the other half -- or of the next
-    // unit's first half -- are in flight.  LDS reads return in order; every count is the number of LDS operations
-    // issued behind the one waited for (or fewer: waiting for more is safe).
-    u32x4 a0[8], a1[8], cw;
+    // Units are software-pipelined over two sets of 8 gathered weight fragments: the gathers of one half of a unit's
+    // k-steps -- or of the next unit's first half -- go out one per step between the MFMA pairs of the other half, so
+    // that a wave's instruction stream is MFMAs throughout (two waves share a SIMD's matrix pipe: whenever one of them
+    // is in a stretch without MFMAs the pipe idles unless the other happens to be in one with).  LDS reads return in
+    // order; every count is the number of LDS operations issued behind the one waited for (or fewer: waiting for more
+    // is safe).
+    u32x4 a0[8], a1[8];
+    uint32_t cw[4], cn[4];   // the lane's 16 code bytes of the current unit's piece, and of the next one's (in flight)
     uint32_t cslot = ring0;
-#define WD_G(A, j, s, sel) if constexpr (ABL & 2) { A[j] = cw; asm volatile("; PQX %0" : "+v"(A[j])); } else A[j] = dc_lds_read16(__builtin_amdgcn_perm(cw[(s) >> 2], img_lane, sel));
+#define WD_G(A, j, s, sel) if constexpr (ABL & 2) { A[j] = u32x4{cw[0], cw[1], cw[2], cw[3]}; asm volatile("; PQX %0" : "+v"(A[j])); } else A[j] = dc_lds_read16(__builtin_amdgcn_perm(cw[(s) >> 2], img_lane, sel));
+// The next piece's codes come as four dword reads into registers of their own, and move into `cw` by instructions
+// written here, behind the wait: a copy the compiler makes of a register whose read is still in flight can land in
+// front of the wait (it knows nothing of the read), and a loop-carried value always needs one.
+#define WD_READ_CODES(slot) { const uint32_t ca_ = (slot) + lane16; cn[0] = wd_lds_read4_at<0>(ca_); cn[1] = wd_lds_read4_at<4>(ca_); cn[2] = wd_lds_read4_at<8>(ca_); cn[3] = wd_lds_read4_at<12>(ca_); }
+#define WD_TAKE_CODES(n)                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(%8)\n\t; PQL %4\n\t; PQL %5\n\t; PQL %6\n\t; PQL %7\n\t"                      \
+                 "v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"                    \
+                 : "=&v"(cw[0]), "=&v"(cw[1]), "=&v"(cw[2]), "=&v"(cw[3])                                              \
+                 : "v"(cn[0]), "v"(cn[1]), "v"(cn[2]), "v"(cn[3]), "n"(n) : "memory");
 #define WD_GLO WD_G(a0, 0, 0, sel0) WD_G(a0, 1, 1, sel1) WD_G(a0, 2, 2, sel2) WD_G(a0, 3, 3, sel3) WD_G(a0, 4, 4, sel0) WD_G(a0, 5, 5, sel1) WD_G(a0, 6, 6, sel2) WD_G(a0, 7, 7, sel3)
 #define WD_GHI WD_G(a1, 0, 8, sel0) WD_G(a1, 1, 9, sel1) WD_G(a1, 2, 10, sel2) WD_G(a1, 3, 11, sel3) WD_G(a1, 4, 12, sel0) WD_G(a1, 5, 13, sel1) WD_G(a1, 6, 14, sel2) WD_G(a1, 7, 15, sel3)
+// (two accumulators per token fragment, even and odd k-steps: an MFMA that adds to the result of the one before it
+// waits for that result -- four pipe passes -- so two chains a wave keep the pipe half busy, four keep it fed)
 #define WD_MM(A, j, s)                                                                                              \
-    if constexpr (ABL & 1) { accA.x += __uint_as_float(A[j].x ^ B0[s].x); accB.x += __uint_as_float(A[j].y ^ B1[s].x); } else { \
-    accA = Act<AT>::mfma16(__builtin_bit_cast(vec8, A[j]), __builtin_bit_cast(vec8, B0[s]), accA);                   \
-    accB = Act<AT>::mfma16(__builtin_bit_cast(vec8, A[j]), __builtin_bit_cast(vec8, B1[s]), accB); }                 \
+    if constexpr (ABL & 1) { accA[(s) & 1].x += __uint_as_float(A[j].x ^ B0[s].x); accB[(s) & 1].x += __uint_as_float(A[j].y ^ B1[s].x); } else { \
+    accA[(s) & 1] = Act<AT>::mfma16(__builtin_bit_cast(vec8, A[j]), __builtin_bit_cast(vec8, B0[s]), accA[(s) & 1]);  \
+    accB[(s) & 1] = Act<AT>::mfma16(__builtin_bit_cast(vec8, A[j]), __builtin_bit_cast(vec8, B1[s]), accB[(s) & 1]); } \
     __builtin_amdgcn_sched_barrier(0);
 #define WD_MW(j, s, n) asm volatile("s_waitcnt lgkmcnt(%1)\n\t; PQL %0" : "+v"(a0[j]) : "n"(n)); WD_MM(a0, j, s)
 #define WD_MN(j, s) WD_MM(a1, j, s)
     // (defined on every path, so that no path gets a compiler-made initialisation behind the first hand-issued reads)
 #pragma unroll
     for (int j = 0; j < 8; ++j) asm volatile("" : "=v"(a0[j]), "=v"(a1[j]));
-    asm volatile("" : "=v"(cw));
+    asm volatile("" : "=v"(cw[0]), "=v"(cw[1]), "=v"(cw[2]), "=v"(cw[3]), "=v"(cn[0]), "=v"(cn[1]), "=v"(cn[2]), "=v"(cn[3]));
     if (has_chunk) {
-        dc_wait_vm(ahead - 1);          // unit 0's piece (the later ones may still be on their way)
-        cw = dc_lds_read16(cslot + lane16);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        dc_landed(cw);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ahead - 1) : "memory");   // unit 0's piece (the later ones may still be on their way)
+        WD_READ_CODES(cslot)
+        WD_TAKE_CODES(0)
         WD_GLO
     }
     WD_STAMP(7)   // first gathers issued
@@ -291,34 +319,35 @@ __global__ __launch_bounds__(WD_WAVES * 64) void gemm_wide_kernel(const WidePara
                 if (i == 1) { WD_RSTAMP(1) }   // first unit done
                 WD_USTAMP(0)
                 dma_unit();             // unit u + ahead into the slot this unit's piece has left
-                f32x4 accA{0.f, 0.f, 0.f, 0.f}, accB{0.f, 0.f, 0.f, 0.f};
-                WD_USTAMP(1)
-                WD_GHI
-                WD_USTAMP(2)
+                f32x4 accA[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accB[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
                 // The next unit's piece: behind it the ahead - 1 younger requests.  The counter also counts the stores
                 // of a round's epilogue, in order with the loads: so that the first unit of a round does not wait for
                 // stores issued a moment ago, the last unit of the round before it has waited for one piece more (this
                 // wait then covers the piece the first unit reads), and the first unit waits for nothing.
-                dc_wait_vm(i == nf - 1 ? ahead - 2 : i == 0 && r > 0 ? 47 : ahead - 1);
+                if (i == nf - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ahead - 2) : "memory");
+                else if (!(i == 0 && r > 0)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ahead - 1) : "memory");
                 const uint32_t nslot = cslot == ring_last ? ring0 : cslot + 1024u;
-                u32x4 cwn = dc_lds_read16(nslot + lane16);
-                WD_USTAMP(3)
-                // behind a0[j]: 7 - j of its set, 8 of the other set, the read above (and the two stores of the unit before)
-                WD_MW(0, 0, 15) WD_MW(1, 1, 15) WD_MW(2, 2, 14) WD_MW(3, 3, 13) WD_MW(4, 4, 12) WD_MW(5, 5, 11) WD_MW(6, 6, 10) WD_MW(7, 7, 9)
+                WD_READ_CODES(nslot)
+                WD_USTAMP(1)
+                // First half of the k-steps: per step the gather of the matching step of the second half goes out, then
+                // the two MFMAs of the step.  Behind a0[j] at its wait: 7 - j of its set, (the two tile stores of the
+                // unit before,) the four reads above and j + 1 of the other set -- at least 12.
+#define WD_S1(j, s, sel) WD_G(a1, j, (s) + 8, sel) WD_MW(j, s, 12)
+                WD_S1(0, 0, sel0) WD_S1(1, 1, sel1) WD_S1(2, 2, sel2) WD_S1(3, 3, sel3)
+                WD_S1(4, 4, sel0) WD_S1(5, 5, sel1) WD_S1(6, 6, sel2) WD_S1(7, 7, sel3)
+#undef WD_S1
                 WD_USTAMP(4)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                dc_landed(cwn);
-#define WD_L1(j) dc_landed(a1[j]);
-                WD_L1(0) WD_L1(1) WD_L1(2) WD_L1(3) WD_L1(4) WD_L1(5) WD_L1(6) WD_L1(7)
-#undef WD_L1
-                cw = cwn;
+                WD_TAKE_CODES(8)         // the next unit's codes: behind them the 8 gathers above
                 cslot = nslot;
                 WD_USTAMP(5)
-                WD_GLO                   // first half of the next unit (of this one again after the last: never used)
-                WD_USTAMP(6)
-                WD_MN(0, 8) WD_MN(1, 9) WD_MN(2, 10) WD_MN(3, 11) WD_MN(4, 12) WD_MN(5, 13) WD_MN(6, 14) WD_MN(7, 15)
-                *reinterpret_cast<f32x4 *>(acc_tiles + ((size_t)(i * WD_WT) * 64 + lane) * 16) = accA;
-                *reinterpret_cast<f32x4 *>(acc_tiles + ((size_t)(i * WD_WT + 1) * 64 + lane) * 16) = accB;
+                // Second half: per step the gather of the NEXT unit's first half (of this unit again after the last:
+                // never used), then the step's MFMAs.  Behind a1[j]: 7 - j of its set and j + 1 of the other: 8.
+#define WD_S2(j, s, sel) WD_G(a0, j, j, sel) asm volatile("s_waitcnt lgkmcnt(8)\n\t; PQL %0" : "+v"(a1[j])); WD_MM(a1, j, s)
+                WD_S2(0, 8, sel0) WD_S2(1, 9, sel1) WD_S2(2, 10, sel2) WD_S2(3, 11, sel3)
+                WD_S2(4, 12, sel0) WD_S2(5, 13, sel1) WD_S2(6, 14, sel2) WD_S2(7, 15, sel3)
+#undef WD_S2
+                *reinterpret_cast<f32x4 *>(acc_tiles + ((size_t)(i * WD_WT) * 64 + lane) * 16) = accA[0] + accA[1];
+                *reinterpret_cast<f32x4 *>(acc_tiles + ((size_t)(i * WD_WT + 1) * 64 + lane) * 16) = accB[0] + accB[1];
                 WD_USTAMP(7)
             }
             // the gathers issued behind the round's last unit: landed before any branch
@@ -404,6 +433,8 @@ __global__ __launch_bounds__(WD_WAVES * 64) void gemm_wide_kernel(const WidePara
         }
     }
 #undef WD_G
+#undef WD_READ_CODES
+#undef WD_TAKE_CODES
 #undef WD_GLO
 #undef WD_GHI
 #undef WD_MM
