@@ -10,7 +10,7 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 echo "[1/6] bench.py"; timeout -k 10 500 python3 "$R/bench.py" > "$O/bench.json"
 echo "[2/6] kernel trace"; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 "$R/bench.py" --no-cpu-baseline --steps 3 --warmup 1 --launch-log "$O/launches.json" > "$O/bench_under_rocprof.json"
-SMALL="--no-cpu-baseline --layers 2 --steps 1 --warmup 1"
+SMALL="--no-cpu-baseline --no-mid --layers 2 --steps 1 --warmup 1"   # (the mid-size batches would mix other launches into the per-grid medians)
 echo "[3/6] pmc FETCH_SIZE"; timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/bench.py" $SMALL > /dev/null
 echo "[4/6] pmc WRITE_SIZE"; timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 "$R/bench.py" $SMALL > /dev/null
 echo "[5/6] pmc SQ"; timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$O/pmc_sq" -- python3 "$R/bench.py" $SMALL > /dev/null

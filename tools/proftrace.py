@@ -15,7 +15,7 @@ import csv
 import glob
 import json
 
-GEMM_MARKS = ("gemm_stream_kernel", "gemm_tiled_kernel", "gemm_decode_kernel", "gemm_generic_kernel")
+GEMM_MARKS = ("gemm_stream_kernel", "gemm_tiled_kernel", "gemm_decode_kernel", "gemm_wide_kernel", "gemm_generic_kernel")
 
 
 def short(name):
