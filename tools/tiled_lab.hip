@@ -70,7 +70,7 @@ float run(const char *label, int T, int N, int G, int nparts) {
 }
 
 // per-block phase stamps (wall_clock64, 100 MHz) of one launch
-template <int WAVES_T, int WN, int WT, int KT>
+template <int WAVES_T, int WN, int WT, int KT, int ABLX = 0>
 void stamps(int T, int N, int G, int nparts) {
     const int K = 256, D = 8, M = 1;
     constexpr int BN = (8 / WAVES_T) * WN * 16, BT = WAVES_T * WT * 16;
@@ -90,8 +90,9 @@ void stamps(int T, int N, int G, int nparts) {
     const int per_xcd = (n_tiles * t_tiles + 7) / 8, nslots = per_xcd < g_slots ? per_xcd : g_slots, nblk = nslots * 8;
     CK(hipMalloc(&st, (size_t)nblk * 64)); CK(hipMemset(st, 0, (size_t)nblk * 64));
     const size_t lds = (size_t)ST_MAX_LDS_CB + 3 * (size_t)KT * BT * TL_BK * 2;
-    auto kern = gemm_tiled_kernel<bf16_t, int8_t, D, M, WAVES_T, WN, WT, KT, 32>;
+    auto kern = gemm_tiled_kernel<bf16_t, int8_t, D, M, WAVES_T, WN, WT, KT, 32 | ABLX>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ABLX) printf("(ablated build %d) ", ABLX);
     // random operands: the clock the chip holds depends on the data
     {
         std::vector<unsigned> hx((size_t)T * G * D / 2), hc(pk_bytes / 4), hb((size_t)nparts * K * D / 2);
@@ -123,6 +124,12 @@ void stamps(int T, int N, int G, int nparts) {
         printf("   %-16s min %6.2f  med %6.2f  mean %6.2f  max %6.2f us\n", names[k], v[0], v[v.size() / 2], sum / v.size(), v.back());
     }
     {
+        std::vector<double> v;
+        for (int b = 0; b < nblk; ++b) v.push_back((h[b * 8 + 7] - h[b * 8 + 2]) / 100.0);
+        std::sort(v.begin(), v.end());
+        printf("   of the first epilogue, until its operands (scales, the next tile's first codes) have landed: med %.2f us\n", v[v.size() / 2]);
+    }
+    {
         std::vector<double> cyc, ghz;
         for (int b = 0; b < nblk; ++b) {
             cyc.push_back((double)(h[b * 8 + 6] - h[b * 8 + 5]));
@@ -148,6 +155,7 @@ int main(int argc, char **argv) {
     if (argc > 3) g_slots = atoi(argv[3]);
     if (argc > 2 && argv[2][0] == 's') {
         stamps<2, 8, 4, 2>(T, 28672, 512, 2);
+        stamps<2, 8, 4, 2, 4>(T, 28672, 512, 2);  // the same without the epilogue's stores
         stamps<2, 8, 4, 2>(T, 4096, 512, 1);      // o_proj: one tile per block
         stamps<2, 8, 4, 2>(T, 4096, 1792, 1);     // down_proj
         return 0;

@@ -121,6 +121,12 @@ struct Act<bf16_t> {
         bf16_t b = (bf16_t)f;  // v_cvt_pk_bf16_f32: nearest even, NaN stays NaN
         return __builtin_bit_cast(uint16_t, b);
     }
+    // two values rounded and packed, a in the low half: one v_cvt_pk_bf16_f32
+    static __device__ inline uint32_t pack2(float a, float b) {
+        typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 h = {(bf16_t)a, (bf16_t)b};
+        return __builtin_bit_cast(uint32_t, h);
+    }
     // element-wise a + b, each sum rounded once to bf16 (nearest even).  gfx950 has no packed bf16 add: per pair of
     // values two unpacks each, ONE packed fp32 add (written on float pairs so that the compiler emits v_pk_add_f32)
     // and one packed conversion -- 6 instructions instead of 7
@@ -153,6 +159,11 @@ struct Act<fp16_t> {
     static __device__ inline uint16_t from_f32(float f) {
         fp16_t b = (fp16_t)f;
         return __builtin_bit_cast(uint16_t, b);
+    }
+    static __device__ inline uint32_t pack2(float a, float b) {
+        typedef fp16_t fp16x2 __attribute__((ext_vector_type(2)));
+        const fp16x2 h = {(fp16_t)a, (fp16_t)b};
+        return __builtin_bit_cast(uint32_t, h);
     }
     static __device__ inline vec8 add8(vec8 a, vec8 b) { return a + b; }   // v_pk_add_f16: correctly rounded
     static __device__ inline f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {

@@ -136,6 +136,17 @@ constexpr int pipe_newer(int g) {   // GR: LDS reads per group's gathers (two fr
     return after;
 }
 
+// One dword of a code piece, requested by inline asm (W: which dword of the lane's 16 bytes).  ACROSS: the request
+// stays in flight across branches ("; PQR" for the lint: nothing that can run between it and its landing may touch the register,
+// whatever the control flow); otherwise no branch may come before it has landed ("; PQI").
+template <int W, bool ACROSS>
+__device__ __forceinline__ uint32_t code_load(uint32_t off, const unsigned char *base) {
+    uint32_t t;
+    if constexpr (ACROSS) asm volatile("; PQR %0\n\tglobal_load_dword %0, %1, %2 offset:%3" : "=v"(t) : "v"(off), "s"(base), "n"(4 * W) : "memory");
+    else asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2 offset:%3" : "=v"(t) : "v"(off), "s"(base), "n"(4 * W) : "memory");
+    return t;
+}
+
 constexpr int TL_THREADS = 512;
 constexpr int TL_WAVES = 8;
 constexpr int TL_BK = 64;    // k per LDS tile
@@ -308,7 +319,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
     // a register with a load in flight never lives across a branch, a join or a loop back edge (where a
     // copy could be inserted); tools/lint_inflight.py checks the generated code for both ("; PQI" marks a
     // hand-issued load or LDS read, "; PQL" the point from which its register may be read).
-    auto load_pieces = [&](piece_t (&dst)[PPU][WN], int u) {
+    auto load_pieces = [&](piece_t (&dst)[PPU][WN], int u, auto across_c) {
+        constexpr bool ACROSS = decltype(across_c)::value;
 #pragma unroll
         for (int pi = 0; pi < PPU; ++pi) {
             const int p = u * PPU + pi;
@@ -316,15 +328,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                 (uint32_t)(p / PIECES) * 1024u + (uint32_t)lane * 16u + (uint32_t)(p % PIECES) * (16u / PIECES);
 #pragma unroll
             for (int i = 0; i < WN; ++i) {
-#pragma unroll
-                for (int w = 0; w < PW; ++w) {
-                    uint32_t t;
-                    if (w == 0) asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
-                    else if (w == 1) asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2 offset:4" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
-                    else if (w == 2) asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2 offset:8" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
-                    else asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2 offset:12" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
-                    dst[pi][i][w] = t;
-                }
+                static_for<PW>([&](auto wc) { dst[pi][i][decltype(wc)::value] = code_load<decltype(wc)::value, ACROSS>(off, fbase[i]); });
             }
         }
     };
@@ -334,11 +338,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
         const int p = u * PPU + pi;
         const uint32_t off =
             (uint32_t)(p / PIECES) * 1024u + (uint32_t)lane * 16u + (uint32_t)(p % PIECES) * (16u / PIECES);
-        uint32_t t;
-        if constexpr (w == 0) asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
-        else if constexpr (w == 1) asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2 offset:4" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
-        else if constexpr (w == 2) asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2 offset:8" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
-        else asm volatile("; PQI %0\n\tglobal_load_dword %0, %1, %2 offset:12" : "=v"(t) : "v"(off), "s"(fbase[i]) : "memory");
+        const uint32_t t = code_load<w, false>(off, fbase[i]);
         dst[pi][i][w] = t;
     };
     constexpr int CL = PPU * WN * PW;                // code loads per loop step
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
         constexpr int BASE = XS ? (mode >> 2) % 3 : 0;
         constexpr int AHEAD = DEEP ? 2 : 1;
         const int ureq = u + AHEAD < nsteps ? u + AHEAD : nsteps - 1;
-        if constexpr (!PIPE) load_pieces(req, ureq);
+        if constexpr (!PIPE) load_pieces(req, ureq, std::integral_constant<bool, false>{});
         auto stage = [&](auto sgc) {     // sgc: the stage's number within the step, a compile-time constant for PIPE
             const int sg = sgc;
             if constexpr (!PIPE) x_issue(u * SPU + sg + 2, buf2);
@@ -755,7 +755,6 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
         const int npin = pin + nslots;
         const bool more = PERSIST && npin < per_xcd && run0 + npin < total;
         const TileSel done = cur_tile;
-        if (more) cur_tile = tile_of(run0 + npin);   // otherwise the requests below re-read this tile: no branch around a load
         pin = npin;
 
         // ---- epilogue: scale, bias, round, store ---------------------------------------------------------------
@@ -769,37 +768,46 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
         // requested before the first is used (one memory round trip for the whole epilogue).  Rows of a fragment are
         // whole or absent (partition sizes are multiples of 16); an absent fragment reads the partition's last rows.
         u32x2 sraw[WN], braw[WN];
+        const bool has_bias = bias && !(ABL & 32);
+        if constexpr (PERSIST) {
+            // Hand-issued, like the main loop's loads, so that one counted wait separates what the epilogue needs now
+            // (scales, bias: usually in the L2) from what only the next tile needs (its first codes, often from HBM,
+            // and its first two stages), which then travel behind the epilogue's arithmetic and stores.  No branch
+            // between the requests and their waits: without a bias its loads re-read the scales.
+            const uint16_t *bsrc = has_bias ? bias : scales;
 #pragma unroll
-        for (int i = 0; i < WN; ++i) {
-            const int nb = done.row0 + (wn * WN + i) * 16 + q * 4;
-            const int nc = nb + 4 <= done.row_end ? nb : done.row_end - 4;
-            sraw[i] = *reinterpret_cast<const u32x2 *>(scales + nc);
-            braw[i] = (bias && !(ABL & 32)) ? *reinterpret_cast<const u32x2 *>(bias + nc) : u32x2{0u, 0u};
-        }
-        if constexpr (PERSIST) {
-        bind(cur_tile);
-        load_pieces_tracked(c0, 0);
-        load_pieces_tracked(c1, nsteps > 1 ? 1 : 0);
-        }
-        // These loads are waited for here, before the DMA goes out: the compiler waits for a tracked load that is
-        // pending beside an LDS-DMA with vmcnt(0), which would put the DMA's latency in front of the epilogue
-        // arithmetic instead of behind it.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int i = 0; i < WN; ++i) {
+                const int nb = done.row0 + (wn * WN + i) * 16 + q * 4;
+                const int nc = nb + 4 <= done.row_end ? nb : done.row_end - 4;
+                asm volatile("; PQI %0\n\tglobal_load_dwordx2 %0, %1, off" : "=v"(sraw[i]) : "v"(scales + nc) : "memory");
+                asm volatile("; PQI %0\n\tglobal_load_dwordx2 %0, %1, off" : "=v"(braw[i]) : "v"(bsrc + nc) : "memory");
+            }
+            // the next tile, worked out while the requests above travel (past the last tile: this one again)
+            cur_tile = tile_of(run0 + (more ? npin : npin - nslots));
+            bind(cur_tile);
+            load_pieces(c0, 0, std::integral_constant<bool, true>{});
+            load_pieces(c1, nsteps > 1 ? 1 : 0, std::integral_constant<bool, true>{});
+            // The ring starts over at slot 0 for every tile, so that the slot of every stage of the unrolled main loop
+            // is a compile-time constant.  The DMA of the two stages past the end of the finished tile may still be
+            // writing the ring; it comes from the same waves as what is issued here and lands first.
+            buf = 0;
+            buf2 = 2;
+            x_issue(0, 0);
+            x_issue(1, 1);
+            static_assert(2 * CL + 2 * KT * PPW < 64, "the wait's count has six bits");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CL + 2 * KT * PPW) : "memory");
 #pragma unroll
-        for (int i = 0; i < WN; ++i) asm volatile("" : "+v"(sraw[i]), "+v"(braw[i]));
-        if constexpr (PERSIST) {
-        landed(c0);
-        landed(c1);
+            for (int i = 0; i < WN; ++i) asm volatile("; PQL %0\n\t; PQL %1" : "+v"(sraw[i]), "+v"(braw[i]));
+        } else {
+#pragma unroll
+            for (int i = 0; i < WN; ++i) {
+                const int nb = done.row0 + (wn * WN + i) * 16 + q * 4;
+                const int nc = nb + 4 <= done.row_end ? nb : done.row_end - 4;
+                sraw[i] = *reinterpret_cast<const u32x2 *>(scales + nc);
+                braw[i] = has_bias ? *reinterpret_cast<const u32x2 *>(bias + nc) : u32x2{0u, 0u};
+            }
         }
-        // The ring starts over at slot 0 for every tile, so that the slot of every stage of the unrolled main loop
-        // is a compile-time constant.  The DMA of the two stages past the end of the finished tile may still be
-        // writing the ring; it comes from the same waves as what is issued here and lands first.
-        if constexpr (PERSIST) {
-        buf = 0;
-        buf2 = 2;
-        x_issue(0, 0);
-        x_issue(1, 1);
-        }
+        if (first) stamp(7);
 
         auto finish = [&](int i, int j, uint32_t &lo, uint32_t &hi) {   // fragment (i, j) -> two packed dwords
             uint16_t h[4];
@@ -813,7 +821,57 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
             lo = h[0] | ((uint32_t)h[1] << 16);
             hi = h[2] | ((uint32_t)h[3] << 16);
         };
-        if constexpr (WN % 2 == 0) {
+        // A wave whose part of the tile lies inside the matrix on both axes (all of them, except along a ragged edge)
+        // takes the short way: no bounds checks, so its stores are exactly WN / 2 * WT and the wait behind them can
+        // leave them in flight; scales applied to pairs of values (v_pk_mul_f32), the bias only where there is one;
+        // one store address per wave, the fragments at constant distances from it.
+        const bool whole = WN % 2 == 0 && done.t0 + (wt * WT + WT) * 16 <= T &&
+                           done.row0 + (wn * WN + WN) * 16 <= done.row_end;
+        auto finish_whole = [&](auto hb_c) {
+            constexpr bool HB = decltype(hb_c)::value;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            auto pair_of = [](uint32_t w) { return f32x2{Act<AT>::to_f32((uint16_t)w), Act<AT>::to_f32((uint16_t)(w >> 16))}; };
+            uint16_t *yp0 = y + (size_t)(done.t0 + wt * WT * 16 + r16) * y_stride + done.row0 + wn * WN * 16 +
+                            ((q & 1) ? 16 + 4 * (q - 1) : 4 * q);
+#pragma unroll
+            for (int ip = 0; ip < WN / 2; ++ip) {
+                f32x2 sc[2][2], bi[2][2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        sc[e][h] = pair_of(sraw[2 * ip + e][h]);
+                        bi[e][h] = HB ? pair_of(braw[2 * ip + e][h]) : f32x2{0.f, 0.f};
+                    }
+#pragma unroll
+                for (int j = 0; j < WT; ++j) {
+                    uint32_t w[2][2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            f32x4 &a = acc[2 * ip + e][j];
+                            f32x2 v = f32x2{a[2 * h], a[2 * h + 1]} * sc[e][h];
+                            if constexpr (HB) v = v + bi[e][h];
+                            w[e][h] = Act<AT>::pack2(v.x, v.y);
+                            a[2 * h] = 0.f;
+                            a[2 * h + 1] = 0.f;
+                        }
+                    const auto sl = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
+                    const auto sh = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+                    const u32x4 o4{sl[0], sh[0], sl[1], sh[1]};
+                    if constexpr (ABL & 4) {
+                        if (o4.x == 0x12344321u && o4.y == 0x43211234u && o4.z == 0x11111111u) yp0[0] = (uint16_t)o4.w;
+                    } else {
+                        *reinterpret_cast<u32x4 *>(yp0 + (size_t)j * 16 * y_stride + ip * 32) = o4;
+                    }
+                }
+            }
+        };
+        if (whole) {
+            if (has_bias) finish_whole(std::integral_constant<bool, true>{});
+            else finish_whole(std::integral_constant<bool, false>{});
+        } else if constexpr (WN % 2 == 0) {
 #pragma unroll
             for (int ip = 0; ip < WN / 2; ++ip) {
                 const int n0 = done.row0 + (wn * WN + 2 * ip) * 16;
@@ -857,16 +915,26 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
             }
         }
         if (first) stamp(3);
-        // the next tile's first stages (and this tile's stores) are done for this wave
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The next tile's first stages have landed for this wave.  The DMA went out before the tile's stores and memory
+        // operations retire in issue order: a wave that took the short way leaves its WN / 2 * WT stores in flight
+        // (they are older than anything the next tile waits for by count), any other waits for everything.
+        if (whole && !(ABL & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WN / 2 * WT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (PERSIST) {
+            landed(c0);
+            landed(c1);
+        }
         if (!more) break;
         if (cur_tile.part != img_part) {             // block-uniform; every wave is past its last gather
             int tid_here = tid;                      // opaque: keeps the image's address arithmetic out of the loop's registers
             asm volatile("" : "+v"(tid_here));
             build_image(cur_tile.part, tid_here);
             img_part = cur_tile.part;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        __syncthreads();
+        // (a plain barrier: __syncthreads() would wait for the stores)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
     stamp(4);
 }
