@@ -50,3 +50,24 @@ int pq_probe_mfma(const void *in, int n_in, void *out, int blocks, int iters, vo
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 }
+
+// Cache probe: block b reads one dword of every 128-byte line of bytes [b * bytes_per_block, (b + 1) * bytes_per_block)
+// of `base` -- the lines reach the L2 of the XCD the block runs on (block b -> XCD b % 8) while 4 bytes of each cross
+// into the CU.  `shift` moves the blocks' regions by that many blocks (a deliberately wrong XCD).
+__global__ __launch_bounds__(64) void probe_touch_kernel(const unsigned char *__restrict__ base, size_t bytes_per_block,
+                                                          size_t total, int shift, uint32_t *__restrict__ sink) {
+    const size_t blk = (blockIdx.x + (size_t)shift) % gridDim.x;
+    const size_t off0 = blk * bytes_per_block;
+    uint32_t acc = 0;
+    for (size_t o = (size_t)threadIdx.x * 128; o < bytes_per_block; o += (size_t)blockDim.x * 128)
+        if (off0 + o + 4 <= total) acc += *reinterpret_cast<const uint32_t *>(base + off0 + o);
+    if (acc == 0x12345678u) sink[0] = acc;   // keeps the loads
+}
+
+extern "C" int pq_probe_touch(const void *base, size_t bytes_per_block, size_t total, int blocks, int shift, void *sink,
+                              void *stream) {
+    if (!base || !sink || blocks < 1) return 1;
+    hipLaunchKernelGGL(probe_touch_kernel, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const unsigned char *>(base), bytes_per_block, total, shift, static_cast<uint32_t *>(sink));
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
