@@ -74,6 +74,16 @@ def test_fused_add_norm_pair_llama3_8b(kin1, parts2, T):
     _check("bf16", res_u, res_f, y_u, y_f, r, y_x, ssq, T, res)
 
 
+@pytest.mark.parametrize("kin1,parts2", [(3584, [7168, 7168]), (3584, [1024, 128, 128])])
+@pytest.mark.parametrize("T", [5, 16])
+def test_fused_add_norm_pair_hidden_8192(kin1, parts2, T):
+    """The per-rank shapes of Llama-3-70B at TP = 8 run as one rank (hidden 8192: the GEMM behind the norm is split
+    along K over two blocks, and a thread adds sixteen fragments' sums of squares for its token)."""
+    from vllm_pq_amd import ops
+    res_u, res_f, y_u, y_f, r, y_x, ssq, res = _chain(ops, T, 8192, kin1, parts2, "bf16", False, 6000 + T)
+    _check("bf16", res_u, res_f, y_u, y_f, r, y_x, ssq, T, res)
+
+
 def _check(dtype, res_u, res_f, y_u, y_f, r, y_x, ssq, T, res):
     ulp = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10       # spacing relative to a value's power of two
     # new residual: one rounding of the exact sum (fused) against two (three steps): each within its own bound
@@ -99,7 +109,8 @@ def _check(dtype, res_u, res_f, y_u, y_f, r, y_x, ssq, T, res):
 
 def test_norm_pair_supported_through_the_method():
     """The plugin-level query: supported for a Llama-3-8B pair at decode sizes, not beyond 128 tokens, not for a
-    hidden size whose sums a block cannot add up (8192), not across a tensor-parallel row-parallel layer."""
+    hidden size whose sums a block cannot add up (16384; 8192 is within reach), not across a tensor-parallel
+    row-parallel layer."""
     from vllm_pq_amd import PQConfig
     from vllm_pq_amd.host.linear import MergedColumnParallelLinear, RowParallelLinear
     qc = PQConfig(8, 8, 1, 1)
@@ -119,7 +130,10 @@ def test_norm_pair_supported_through_the_method():
     assert not m.norm_pair_supported(o, gu, 129)
     big = make(RowParallelLinear, 512, 8192)
     gu8 = make(MergedColumnParallelLinear, 8192, [64, 64])
-    assert not m.norm_pair_supported(big, gu8, 16)
+    assert m.norm_pair_supported(big, gu8, 16)
+    huge = make(RowParallelLinear, 512, 16384)
+    gu16 = make(MergedColumnParallelLinear, 16384, [64, 64])
+    assert not m.norm_pair_supported(huge, gu16, 16)
     # preferred: whenever supported up to 48 tokens; beyond, only where the plain dispatch runs both layers on the
     # decode kernel anyway
     assert m.norm_pair_preferred(o, gu, 16) and m.norm_pair_preferred(o, gu, 48)

@@ -466,6 +466,10 @@ def test_square_sweep_formats_full_size(ops, hidden, K, d, T):
 
     y = run(x)
     w = ops.pq_dequant(codes, cb, parts)
+    # the dequantised weight the reference is built from is itself checked: torch's own gather, bit for bit
+    idx = (codes[:, :, 0].long() & (K - 1)).reshape(-1)
+    assert torch.equal(w, cb[0, :, 0, :].index_select(0, idx).view(N, hidden))
+    del idx
     ref = (x.float() @ w.float().t()) * scales.view(1, -1).float()
     rms = ref.pow(2).mean().sqrt()
     tol = 0.51 * 2.0 ** -7 * ref.abs() + 1e-4 * rms

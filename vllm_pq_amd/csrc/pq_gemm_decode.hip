@@ -117,8 +117,8 @@ bool gemm_decode_norm_supported(const GemmArgs &a) {
         return (uint64_t)a.T * (uint64_t)n.res_stride * 2 < (1ull << 31);
     }
     if (n.role == 2) {
-        // every thread adds at most eight fragments' sums for its token
-        return n.ssq && n.hidden == a.G * a.d && n.hidden % 16 == 0 && n.hidden / 16 <= 8 * (g.waves * 4);
+        // every thread adds at most DC_SSQ_LOADS fragments' sums for its token (8192 inputs with a block of 8 waves)
+        return n.ssq && n.hidden == a.G * a.d && n.hidden % 16 == 0 && n.hidden / 16 <= DC_SSQ_LOADS * (g.waves * 4);
     }
     return false;
 }

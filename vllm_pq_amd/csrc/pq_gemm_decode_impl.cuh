@@ -39,6 +39,7 @@ namespace pq {
 constexpr int DC_MAX_WAVES = 8;
 constexpr int DC_MAX_TOKENS = 128;                // batches beyond 16 tokens run as groups of 16 over gridDim.z
 constexpr int DC_UMAX = 8;                       // units of a wave (chunks x fragments): 1 KiB of staging each
+constexpr int DC_SSQ_LOADS = 16;                // per-fragment sums of squares a thread adds for its token: hidden <= 16 * 16 * threads / 16
 constexpr int DC_STAGE_BYTES = DC_MAX_WAVES * DC_UMAX * 1024;
 // A token's KiB of a chunk in LDS, padded by two 16-byte slots: ds_read_b128 serves lanes {0-3, 12-15, 20-27} (and
 // the three like groups) in one cycle each, i.e. 8 tokens c at k-octet q and the other 8 at q + 1; with rows
@@ -238,14 +239,14 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
     }
 
     // MODE 2: this thread's share of the per-fragment sums of squares of its token (tid & 15): fragments tid >> 4,
-    // + threads / 16, ... (at most eight: checked on the host), requested here and added once the activations have
-    // landed
-    float ssq_v[8];
+    // + threads / 16, ... (at most DC_SSQ_LOADS: checked on the host), requested here and added once the activations
+    // have landed
+    float ssq_v[DC_SSQ_LOADS];
     if constexpr (MODE == 2) {
         const int fstep = (int)(blockDim.x >> 4);
         const float *sp = p.ssq + tok0 + (tid & 15);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < DC_SSQ_LOADS; ++j) {
             const int f = (tid >> 4) + j * fstep;
             ssq_v[j] = sp[(size_t)(f < p.ssq_frags ? f : p.ssq_frags - 1) * p.t_pad];
         }
@@ -311,9 +312,9 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
         // 8 waves' sums in order.  A block of 8 / R waves plays R of those waves per wave: its k-th load belongs to
         // row (tid >> 4) + (k mod R) * rows of the block.
         const int fstep = (int)(blockDim.x >> 4);
-        float v[8];
+        float v[DC_SSQ_LOADS];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < DC_SSQ_LOADS; ++j) {
             asm volatile("" : "+v"(ssq_v[j]));      // used from here on: behind the wait for the activations
             v[j] = ((tid >> 4) + j * fstep < p.ssq_frags) ? ssq_v[j] : 0.f;
         }
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(DC_MAX_WAVES * 64) void gemm_decode_kernel(const De
             for (int r = 0; r < R; ++r) {
                 float s = 0.f;
 #pragma unroll
-                for (int k = r; k < 8; k += R) s += v[k];
+                for (int k = r; k < DC_SSQ_LOADS; k += R) s += v[k];
                 s += __shfl_xor(s, 16);
                 s += __shfl_xor(s, 32);
                 if (lane < 16) aux[(wave + r * (8 / R)) * 16 + lane] = s;
