@@ -147,6 +147,15 @@ __device__ __forceinline__ uint32_t code_load(uint32_t off, const unsigned char 
     return t;
 }
 
+// Builds of the epilogue, for A/B runs: 0 = bounds-checked arithmetic, every wait for everything; 1 = + the short way
+// for whole tiles; 2 (the library's) = + stores left in flight behind a counted wait, plain barrier; 3 = + hand-issued
+// scale / code loads with one counted wait.  On one device all four give the same launch time within 0.3 %
+// (profiles/r03_epilogue_ab.txt) although 3 shortens the epilogue itself by 0.7 us a tile: the launch runs at the clock
+// the chip's power limit allows, and time taken out of the idle phases comes back as a lower clock.
+#ifndef TL_EPI
+#define TL_EPI 2
+#endif
+
 constexpr int TL_THREADS = 512;
 constexpr int TL_WAVES = 8;
 constexpr int TL_BK = 64;    // k per LDS tile
@@ -769,7 +778,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
         // whole or absent (partition sizes are multiples of 16); an absent fragment reads the partition's last rows.
         u32x2 sraw[WN], braw[WN];
         const bool has_bias = bias && !(ABL & 32);
-        if constexpr (PERSIST) {
+        if constexpr (PERSIST && TL_EPI >= 3) {
             // Hand-issued, like the main loop's loads, so that one counted wait separates what the epilogue needs now
             // (scales, bias: usually in the L2) from what only the next tile needs (its first codes, often from HBM,
             // and its first two stages), which then travel behind the epilogue's arithmetic and stores.  No branch
@@ -806,6 +815,26 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
                 sraw[i] = *reinterpret_cast<const u32x2 *>(scales + nc);
                 braw[i] = has_bias ? *reinterpret_cast<const u32x2 *>(bias + nc) : u32x2{0u, 0u};
             }
+            if constexpr (PERSIST) {
+                cur_tile = tile_of(run0 + (more ? npin : npin - nslots));
+                bind(cur_tile);
+                load_pieces_tracked(c0, 0);
+                load_pieces_tracked(c1, nsteps > 1 ? 1 : 0);
+            }
+            // These loads are waited for here, before the DMA goes out: the compiler waits for a tracked load that is
+            // pending beside an LDS-DMA with vmcnt(0), which would put the DMA's latency in front of the epilogue
+            // arithmetic instead of behind it.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < WN; ++i) asm volatile("" : "+v"(sraw[i]), "+v"(braw[i]));
+            if constexpr (PERSIST) {
+                landed(c0);
+                landed(c1);
+                buf = 0;
+                buf2 = 2;
+                x_issue(0, 0);
+                x_issue(1, 1);
+            }
         }
         if (first) stamp(7);
 
@@ -825,7 +854,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
         // takes the short way: no bounds checks, so its stores are exactly WN / 2 * WT and the wait behind them can
         // leave them in flight; scales applied to pairs of values (v_pk_mul_f32), the bias only where there is one;
         // one store address per wave, the fragments at constant distances from it.
-        const bool whole = WN % 2 == 0 && done.t0 + (wt * WT + WT) * 16 <= T &&
+        const bool whole = TL_EPI >= 1 && WN % 2 == 0 && done.t0 + (wt * WT + WT) * 16 <= T &&
                            done.row0 + (wn * WN + WN) * 16 <= done.row_end;
         auto finish_whole = [&](auto hb_c) {
             constexpr bool HB = decltype(hb_c)::value;
@@ -918,7 +947,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
         // The next tile's first stages have landed for this wave.  The DMA went out before the tile's stores and memory
         // operations retire in issue order: a wave that took the short way leaves its WN / 2 * WT stores in flight
         // (they are older than anything the next tile waits for by count), any other waits for everything.
-        if (whole && !(ABL & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WN / 2 * WT) : "memory");
+        if (TL_EPI >= 2 && whole && !(ABL & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WN / 2 * WT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (PERSIST) {
             landed(c0);
@@ -933,8 +962,12 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         // (a plain barrier: __syncthreads() would wait for the stores)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        if constexpr (TL_EPI >= 2) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            __syncthreads();
+        }
     }
     stamp(4);
 }
