@@ -140,3 +140,13 @@ def test_inflight_lint_catches_violations(tmp_path):
         got[name] = lint.lint(str(f))
     assert got["clean"] == 0
     assert all(got[k] >= 1 for k in ("read", "write", "branch", "never_landed")), got
+    # "; PQR": in flight across branches, checked along the control flow -- a block laid out behind the landing marker
+    # that touches the register is found, the same block left alone is not
+    head_r = ("kern2:\n\t; PQR v5\n\tglobal_load_dword v5, v1, s[2:3]\n\ts_cbranch_scc1 .LBB1_2\n"
+              "\tv_add_u32_e32 v3, v1, v2\n.LBB1_1:\n\ts_waitcnt vmcnt(0)\n\t; PQL v5\n\tv_mov_b32_e32 v6, v5\n\ts_endpgm\n.LBB1_2:\n")
+    for name, tail, want in (("reach_clean", "\tv_mov_b32_e32 v7, v1\n\ts_branch .LBB1_1\n", 0),
+                             ("reach_touch", "\tv_mov_b32_e32 v7, v5\n\ts_branch .LBB1_1\n", 1)):
+        f = tmp_path / (name + ".s")
+        f.write_text(head_r + tail)
+        assert lint.lint(str(f)) == 0, name          # the scan in text order cannot see the block behind the marker
+        assert (lint.lint_reach(str(f)) >= 1) == bool(want), name

@@ -79,8 +79,9 @@ def lint(path):
         if not inflight:
             continue
         if op.startswith("s_cbranch") or op in ("s_branch", "s_setpc_b64", "s_endpgm"):
-            # (s_endpgm itself is harmless: the hardware waits for the wave's outstanding memory operations first)
-            held = set(inflight) - across if op != "s_endpgm" else set()
+            # (a "; PQX" / "; PQR" load still in flight at s_endpgm is harmless: the hardware waits for the wave's
+            # outstanding memory operations first; a "; PQI" one that never landed is a forgotten marker)
+            held = set(inflight) - across
             if held:
                 print(f"{path}:{ln}: [{func}] {op} with loads in flight into v{sorted(held)}")
                 bad += 1
