@@ -158,8 +158,24 @@ class Graph:
     def __init__(self, fn, **capture_args):
         self.g = torch.cuda.CUDAGraph()
         n0 = len(LAUNCH_LOG) if LAUNCH_LOG is not None else 0
-        with torch.cuda.graph(self.g, **capture_args):
-            self.out = fn()
+        # Capture by hand rather than with torch.cuda.graph(): when the captured function fails (a collective that
+        # cannot be captured), that context manager's exit raises from capture_end and leaves the capturing side stream
+        # current, so that the next GPU call of the process fails too.  Here the stream context always unwinds.
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.g.capture_begin(**capture_args)
+            try:
+                self.out = fn()
+            except BaseException:
+                try:
+                    self.g.capture_end()
+                except Exception:
+                    pass
+                raise
+            self.g.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
         self.logged = LAUNCH_LOG[n0:] if LAUNCH_LOG is not None else []
         if LAUNCH_LOG is not None:
             del LAUNCH_LOG[n0:]            # capture launches nothing
@@ -521,6 +537,39 @@ def mfma_ceiling(device, dtype, seconds=1.5):
     return flops * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12
 
 
+def library_gemm(layer, T, device, dtype, k_flops, reps=20):
+    """The dense problem the fused kernel replaces, run by the vendor's library in the same process on the same device:
+    y = x @ W^T with W the layer's dequantised weight in the act dtype (torch.matmul -> hipBLASLt / rocBLAS), and the
+    dequantisation that route needs first (the reference's path above 6 tokens, aqlm.py:141-145).  A yardstick for the
+    clock the chip holds on this kind of data, not part of the product path."""
+    from vllm_pq_amd import ops
+    parts = list(layer.codebooks.output_partition_sizes)
+    w = ops.pq_dequant(layer.codes, layer.codebooks, parts)
+    x = torch.randn(T, w.shape[1], device=device).to(dtype)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) * 1e-3 / reps
+            best = t if best is None else min(best, t)
+        return best
+    t_mm = timed(lambda: torch.matmul(x, w.t()))
+    t_dq = timed(lambda: ops.pq_dequant(layer.codes, layer.codebooks, parts))
+    return {"gemm_us": t_mm * 1e6, "gemm_tflops": k_flops / t_mm / 1e12, "dequant_us": t_dq * 1e6,
+            "dequant_plus_gemm_us": (t_mm + t_dq) * 1e6,
+            "what": "torch.matmul (hipBLASLt / rocBLAS) on the layer's dequantised weight, same shapes, same run; "
+                    "pq_dequant of the layer: the two steps of the reference's route at this batch size"}
+
+
 def profiled_traffic(key):
     """(HBM bytes per launch of a kernel, where the number comes from): measured by the committed rocprofv3 counter
     passes (profiles/traffic_r*.json, newest round first) -- not in this run, PMC counters need the profiler --;
@@ -574,6 +623,10 @@ def split_times(stack, inputs, T, steps, warmup, device, dtype, dist_on, use_gra
 
 def measure(stack, T, steps, warmup, device, dtype, world, dist_on, use_graph, split=False):
     inputs = make_inputs(stack[0], T, device, dtype)
+    if dist_on:         # the ranks start a measurement together (rank 0 alone ran the single-rank probes before)
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        dist.barrier()
     runner = StepRunner(lambda: run_step(stack, inputs), use_graph, dist_on)
     dt = timed_steps(runner, steps, warmup, dist_on)
     per_step = dt / steps
@@ -660,6 +713,9 @@ def main():
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-neighbours", action="store_true", help="skip the element-wise kernels' measurement")
     ap.add_argument("--no-mid", action="store_true", help="skip the mid-size batches (128 and 256 tokens per linear)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="with --gpus > 1 on a box with ONE GPU: every rank uses device 0 and the collectives go through "
+                         "gloo -- the multi-rank code path end to end, its numbers meaningless (the line says so)")
     ap.add_argument("--dry-ranks", action="store_true",
                     help="every rank prints its RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as one JSON line and exits "
                          "without touching a GPU (exercises the rank launcher)")
@@ -668,6 +724,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process never touches a GPU, it starts the N ranks and waits
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("PQ_BENCH_TRACE_AFTER"):      # diagnosis of a hang: every thread's stack after so many seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PQ_BENCH_TRACE_AFTER"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -681,8 +740,9 @@ def main():
         return
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no ROCm device is visible")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.rehearse_one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
 
     import torch.distributed as dist
@@ -690,21 +750,33 @@ def main():
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         parallel_state.initialize_model_parallel(world)
         if args.xgmi_allreduce and world > 1:
             parallel_state.enable_xgmi_all_reduce()
 
+    t_start = time.perf_counter()
+
+    def note(what):     # progress on stderr: a run that stops shows where (stdout carries the JSON line only)
+        print(f"[bench] rank {rank}: {what} ({time.perf_counter() - t_start:.1f} s)", file=sys.stderr, flush=True)
+
     from vllm_pq_amd import ops
     stack = build_stack(world, device, dtype, layers=args.layers)
+    note("stack built")
     T = args.tokens
     if args.launch_log:
         enable_launch_log(stack, dtype)
     # a step is one HIP graph replay, collectives included: 128 GEMM launches and 64 all-reduces issued from Python
     # would make a decode step host-bound
     use_graph = not args.no_graph and (world == 1 or not args.eager_collectives)
+    if args.rehearse_one_gpu and world > 1:
+        use_graph = False       # a gloo collective cannot be captured, and one that fails half-way inside a capture leaves the ranks out of step
 
     main_m = measure(stack, T, args.steps, args.warmup, device, dtype, world, dist_on, use_graph, args.split_times)
+    note(f"{T}-token steps timed")
 
     # dominant kernel: gate_up_proj (largest share of FLOPs and of code bytes)
     dom = "gate_up_proj"
@@ -734,6 +806,13 @@ def main():
                                         "what": "bare v_mfma_f32_16x16x32_bf16 loop, normal operands in registers, "
                                                 "2 waves per SIMD, after 1.5 s of load"}
 
+    if roof["bound"] == "mfma" and rank == 0 and world == 1:
+        lg = library_gemm(stack[0][dom], T, device, dtype, k_flops)
+        lg["fused_over_library"] = lg["gemm_us"] / roof["launch_us"]
+        lg["fused_over_dequant_plus_library"] = lg["dequant_plus_gemm_us"] / roof["launch_us"]
+        roof["library_gemm"] = lg
+
+    note("dominant launch timed")
     decode = None
     if not args.no_decode and args.decode_tokens != T:
         Td = args.decode_tokens
@@ -755,6 +834,7 @@ def main():
                                                               dom_parts, packed=dom_packed) + ":" + dom,
                                "launch_us": t_kd * 1e6}}
 
+    note("decode steps timed")
     neighbours = None
     if not args.no_neighbours:
         neighbours = {f"T{T}": time_neighbours(T, device, dtype, world)}
@@ -771,6 +851,7 @@ def main():
     if world == 1 and not args.no_mid:
         mid = mid_batches(stack, device, dtype)
 
+    note("neighbours, chain and mid-size batches timed")
     # the peer-buffer all-reduce's status word after everything timed: a wait that gave up poisons its output and stays on record
     ar_status = None
     if world > 1 and parallel_state._XGMI_AR is not None:
@@ -805,6 +886,8 @@ def main():
         }
         if ar_status is not None:
             line["pq_ar_status"] = ar_status
+        if args.rehearse_one_gpu:
+            line["rehearsal"] = "all ranks on one GPU, collectives through gloo: code path only, the numbers mean nothing"
         if main_m["split"]:
             line.update(main_m["split"])
         print(json.dumps(line), flush=True)
