@@ -879,7 +879,7 @@ def main():
                        "tokens_per_step": T, "parallelism": f"tp{world}", "launch": main_m["launch"],
                        "apply_calls_per_step": 4 * len(stack),
                        "tokens_per_s_covers": "the PQ linear layers only (no attention, norms, sampling): tokens of a "
-                                              "step / step time of the 128 apply() calls"},
+                                              "step / step time of the %d apply() calls" % (4 * len(stack))},
             "hbm_gbps": main_m["gbps"], "tokens_per_s": main_m["tokens_per_s"],
             "roofline": roof, "cpu_baseline": cpu, "decode": decode, "neighbours": neighbours,
             "layer_chain": chain, "mid_batches": mid,
