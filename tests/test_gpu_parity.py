@@ -700,3 +700,60 @@ def test_min_capability_passes_on_this_device():
     major, minor = torch.cuda.get_device_capability(0)
     assert major * 10 + minor >= PQConfig.get_min_capability(), (major, minor)
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+# ---- 16-entry codebooks folded in pairs -----------------------------------------------------------------
+@pytest.mark.parametrize("d", [2, 4])
+@pytest.mark.parametrize("T", [1, 16, 100, 512])
+def test_folded_pairs_same_weights_and_outputs(ops, d, T):
+    """ops.fold_pairs restates a 16-entry format with 256-entry codebooks of twice the sub-vector length: the
+    dequantised weight is the same bit for bit, and the packed GEMM on the folded tensors meets the same bound against
+    the fp32 reference as the unfolded launch does (different kernels, same weights)."""
+    torch.manual_seed(7 * d + T)
+    parts, Kin = [256, 128, 128], 2048
+    N, G = sum(parts), Kin // d
+    codes = torch.randint(-128, 128, (N, G, 1), dtype=torch.int8, device=DEV)       # stored values reduce mod 16
+    cb = torch.randn(len(parts), 16, 1, d, device=DEV).to(torch.bfloat16)
+    scales = (torch.rand(N, 1, 1, 1, device=DEV) + 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV).to(torch.bfloat16)
+    x = torch.randn(T, Kin, device=DEV).to(torch.bfloat16)
+    codes2, cb2 = ops.fold_pairs(codes, cb)
+    assert codes2.shape == (N, G // 2, 1) and cb2.shape == (len(parts), 256, 1, 2 * d)
+    w = ops.pq_dequant(codes, cb, parts)
+    assert torch.equal(ops.pq_dequant(codes2, cb2, parts), w)
+    packed = ops.pq_repack_codes(codes, cb, parts)
+    packed2 = ops.pq_repack_codes(codes2, cb2, parts)
+    assert packed2.numel() * 2 == packed.numel()
+    ref = (x.float() @ w.float().t()) * scales.view(1, -1).float() + bias.float()
+    tol = 0.51 * 2.0 ** -7 * ref.abs() + 1e-4 * ref.pow(2).mean().sqrt()
+    for y in (ops.pq_gemm_packed(x, packed, codes, cb, scales, parts, bias),
+              ops.pq_gemm_packed(x, packed2, codes2, cb2, scales, parts, bias)):
+        assert ((y.float() - ref).abs() <= tol).all()
+    assert ops.fold_pairs(codes[:, : G - 1], cb) is None                            # odd number of groups
+    assert ops.fold_pairs(codes, torch.randn(len(parts), 256, 1, d, device=DEV).to(torch.bfloat16)) is None
+
+
+def test_folded_pairs_through_the_method(ops):
+    """A layer with 16-entry codebooks of d = 4: process_weights_after_loading folds it, apply() runs the d = 8
+    kernels and returns what the unfolded operator call returns within the rounding of either."""
+    from vllm_pq_amd import PQConfig
+    from vllm_pq_amd.host.linear import MergedColumnParallelLinear
+    qc = PQConfig(4, 4, 1, 1)
+    layer = MergedColumnParallelLinear(1024, [512, 512], bias=False, params_dtype=torch.bfloat16, quant_config=qc)
+    layer.codes.data = torch.randint(-128, 128, layer.codes.shape, dtype=torch.int8)
+    layer.codebooks.data = torch.randn(layer.codebooks.shape).to(torch.bfloat16)
+    layer.scales.data = (torch.rand(layer.scales.shape) + 0.5).to(torch.bfloat16)
+    layer.to(DEV)
+    layer.quant_method.process_weights_after_loading(layer)
+    assert layer.pq_folded is not None and layer.pq_folded[1].shape[1:] == (256, 1, 8)
+    for T in (3, 16, 300):
+        x = torch.randn(T, 1024, device=DEV).to(torch.bfloat16)
+        y, _ = layer(x)
+        w = ops.pq_dequant(layer.codes, layer.codebooks, [512, 512])
+        ref = (x.float() @ w.float().t()) * layer.scales.view(1, -1).float()
+        tol = 0.51 * 2.0 ** -7 * ref.abs() + 1e-4 * ref.pow(2).mean().sqrt()
+        assert ((y.float() - ref).abs() <= tol).all()
+        act = layer.quant_method.apply_silu_and_mul(layer, x)
+        want = torch.empty_like(act)
+        ops.silu_and_mul(want, y)
+        assert (act.float() - want.float()).abs().max() <= 2.0 ** -6 * want.float().abs().max()

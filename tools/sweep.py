@@ -20,6 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_pq_amd import ops  # noqa: E402
 
 HBM, MFMA = 8e12, 2.5e15
+FOLD = True
 MODEL_SHAPES = [
     ("8B.qkv", [4096, 1024, 1024], 4096), ("8B.o", [4096], 4096),
     ("8B.gate_up", [14336, 14336], 4096), ("8B.down", [4096], 14336),
@@ -47,6 +48,12 @@ def point(w, name, parts, kin, K, d, T, dt, reps, budget_bytes):
             codes = torch.randint(lo, hi, (N, G, 1), device=dev, dtype=torch.int32).to(idt)
             cbk = torch.randn(len(parts), K, 1, d, device=dev).to(dt)
             sc = (torch.rand(N, 1, 1, 1, device=dev) + 0.5).to(dt)
+            # as the linear method does at load time: 16-entry codebooks folded in pairs (ops.fold_pairs) -- what is
+            # launched is the format with 256 entries and twice the sub-vector length; the row keeps the original
+            # format's name and algorithmic bytes
+            folded = ops.fold_pairs(codes, cbk) if FOLD else None
+            if folded is not None:
+                codes, cbk = folded
             w["sets"].append((codes, cbk, sc, ops.pq_repack_codes(codes, cbk, parts)))
     sets = w["sets"]
     x = torch.randn(T, kin, device=dev).to(dt)
@@ -79,7 +86,10 @@ def point(w, name, parts, kin, K, d, T, dt, reps, budget_bytes):
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e-3 / n_launch)
     byts = N * G * cb + len(parts) * K * d * 2 + N * 2 + T * kin * 2 + T * N * 2
-    kern = ops.gemm_kernel_name(T, N, G, 1, K, d, cb, dt, parts, packed=sets[0][3] is not None)
+    kc, kb = sets[0][0], sets[0][1]
+    kern = ops.gemm_kernel_name(T, N, kc.shape[1], 1, kb.shape[1], kb.shape[3], cb, dt, parts, packed=sets[0][3] is not None)
+    if kb.shape[1] != K:
+        kern += "(folded)"
     bound = "mfma" if flops / MFMA >= byts / HBM else "hbm"
     frac = max(flops / MFMA, byts / HBM) / best
     return dict(shape=name, N=N, Kin=kin, K=K, d=d, T=T, kernel=kern, us=best * 1e6, bytes=byts, flops=flops,
@@ -95,7 +105,10 @@ def main():
     ap.add_argument("--cache-mb", type=int, default=400, help="bytes of codes to rotate over")
     ap.add_argument("--only", default="", help="comma-separated substrings: only the shapes whose name holds one")
     ap.add_argument("--ts", default="", help="comma-separated token counts instead of the full grid")
+    ap.add_argument("--no-fold", action="store_true", help="run 16-entry formats as they are, without folding pairs of groups")
     args = ap.parse_args()
+    global FOLD
+    FOLD = not args.no_fold
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
     grid = [(n, p, kin, 256, 8) for (n, p, kin) in MODEL_SHAPES]
     if not args.quick:

@@ -411,6 +411,30 @@ def pq_repack_codes(codes: torch.Tensor, codebooks: torch.Tensor,
     return packed
 
 
+def fold_pairs(codes: torch.Tensor, codebooks: torch.Tensor):
+    """A format with 16-entry codebooks restated with 256-entry ones, bit for bit: two neighbouring groups of
+    `d` features become one group of `2 d` whose entry is the two original entries side by side,
+        W[o, 2 d g' : 2 d (g' + 1)] = concat(cb[c[o, 2 g']], cb[c[o, 2 g' + 1]]) = cb2[c[o, 2 g'] + 16 c[o, 2 g' + 1]],
+    so the layer runs on the kernels of the format with twice the sub-vector length (16 entries x d = 4 becomes
+    256 entries x d = 8: the decode, mid-batch and hand-pipelined prefill kernels; half the code bytes).  Returns
+    (codes2 [N, G / 2, 1] int8, codebooks2 [partitions, 256, 1, 2 d]) to hand to pq_repack_codes and the packed entry
+    points in place of the originals, or None when the format cannot be folded (one codebook of 16 entries, one-byte
+    codes, an even number of groups, d = 2 or 4).  Load-time work: a few tensor operations on the device."""
+    if codes.dim() != 3 or codebooks.dim() != 4 or codes.shape[2] != 1 or codebooks.shape[2] != 1:
+        return None
+    N, G, _ = codes.shape
+    K, d = codebooks.shape[1], codebooks.shape[3]
+    if K != 16 or d not in (2, 4) or G % 2 or codes.dtype != torch.int8:
+        return None
+    idx = codes[:, :, 0].to(torch.int16) & 15                      # index = stored value mod K (aqlm.py:32-34)
+    both = idx[:, 0::2] | (idx[:, 1::2] << 4)                      # 0 .. 255
+    codes2 = both.to(torch.uint8).view(torch.int8).unsqueeze(-1).contiguous()
+    e = torch.arange(256, device=codebooks.device)
+    cb = codebooks[:, :, 0, :]                                     # [P, 16, d]
+    codebooks2 = torch.cat((cb[:, e & 15, :], cb[:, e >> 4, :]), dim=-1).unsqueeze(2).contiguous()
+    return codes2, codebooks2
+
+
 def pq_dequant(codes: torch.Tensor, codebooks: torch.Tensor, codebook_partition_sizes: List[int],
                scales: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Dense [out_features, in_features] weight.  With scales=None: same signature and result as

@@ -176,15 +176,29 @@ class PQLinearMethod(LinearMethodBase):
         layer.pq_packed_codes = None
         layer.pq_prepared = None
         layer.pq_dequant_route = False
+        layer.pq_folded = None
         if layer.codes.is_cuda:
             parts = getattr(layer.codebooks, "output_partition_sizes", [])
-            layer.pq_packed_codes = ops.pq_repack_codes(layer.codes.data, layer.codebooks.data, parts)
+            # 16-entry codebooks: neighbouring groups folded in pairs, the same weights as a 256-entry format of twice
+            # the sub-vector length (ops.fold_pairs), which is what the packed entry points then see
+            folded = None if isinstance(self, PQEmbeddingMethod) else ops.fold_pairs(layer.codes.data, layer.codebooks.data)
+            if folded is not None:
+                codes2, codebooks2 = folded
+                packed2 = ops.pq_repack_codes(codes2, codebooks2, parts)
+                if packed2 is not None:
+                    # (of the folded codes only shape, dtype and device are read from here on)
+                    meta = torch.zeros(1, dtype=codes2.dtype, device=codes2.device).expand(codes2.shape)
+                    layer.pq_folded = (meta, codebooks2)
+                    layer.pq_packed_codes = packed2
+            if layer.pq_packed_codes is None:
+                layer.pq_packed_codes = ops.pq_repack_codes(layer.codes.data, layer.codebooks.data, parts)
             # Formats no MFMA kernel takes (a codebook that does not fit LDS, such as AQLM's 1x16 with 65536
             # entries) run on the generic one-wave-per-row kernel: fine for a few tokens, far too slow for a
             # prefill.  Larger batches take the route the reference's own fast path takes there
             # (optimized_dequantize_gemm, aqlm.py:132-156): dequantise, then a dense GEMM.
-            N, G, M = layer.codes.shape
-            K, d = layer.codebooks.shape[1], layer.codebooks.shape[3]
+            pc, pcb = self._packed_operands(layer)      # the format the packed entry points see
+            N, G, M = pc.shape
+            K, d = pcb.shape[1], pcb.shape[3]
             layer.pq_dequant_route = ops.gemm_kernel_name(
                 64, N, G, M, K, d, layer.codes.element_size(), layer.codebooks.dtype, parts or [N],
                 packed=layer.pq_packed_codes is not None) == "generic"
@@ -200,6 +214,14 @@ class PQLinearMethod(LinearMethodBase):
                        for T in (16, 128)):
                     ops.ensure_workspace(layer.codes.device)
 
+    @staticmethod
+    def _packed_operands(layer: torch.nn.Module):
+        """(codes, codebooks) that go with layer.pq_packed_codes: the layer's own, or the folded pair."""
+        folded = getattr(layer, "pq_folded", None)
+        if folded is not None:
+            return folded
+        return layer.codes, layer.codebooks
+
     def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         codebooks = layer.codebooks
         parts = getattr(codebooks, "output_partition_sizes", [])
@@ -207,8 +229,9 @@ class PQLinearMethod(LinearMethodBase):
         if packed is not None:
             # the layer's launch arguments, validated once and again whenever a weight tensor has been replaced
             desc = getattr(layer, "pq_prepared", None)
-            if desc is None or not desc.matches(packed, codebooks.data, layer.scales.data):
-                desc = layer.pq_prepared = ops.PackedLinear(packed, layer.codes.data, codebooks.data, layer.scales.data, parts)
+            pc, pcb = self._packed_operands(layer)
+            if desc is None or not desc.matches(packed, pcb.data, layer.scales.data):
+                desc = layer.pq_prepared = ops.PackedLinear(packed, pc.data, pcb.data, layer.scales.data, parts)
             return ops.pq_gemm_packed_prepared(desc, x, bias)
         if getattr(layer, "pq_dequant_route", False) and x.numel() // x.shape[-1] > GENERIC_KERNEL_MAX_TOKENS:
             # the reference's order for this route (aqlm.py:143-156): without bias the GEMM output is scaled,
@@ -234,7 +257,8 @@ class PQLinearMethod(LinearMethodBase):
             out = torch.empty(y.shape[:-1] + (y.shape[-1] // 2,), dtype=y.dtype, device=y.device)
             ops.silu_and_mul(out, y)
             return out
-        return ops.pq_gemm_packed_silu_mul(x, packed, layer.codes, layer.codebooks, layer.scales, bias)
+        pc, pcb = self._packed_operands(layer)
+        return ops.pq_gemm_packed_silu_mul(x, packed, pc, pcb, layer.scales, bias)
 
 
     # ---- a fused add + RMSNorm between two PQ linears (decode batches, no tensor parallelism on the first) ----
@@ -248,9 +272,11 @@ class PQLinearMethod(LinearMethodBase):
             return False            # the sum over ranks comes between the GEMM and the add
         pf = getattr(first.codebooks, "output_partition_sizes", [])
         ps = getattr(second.codebooks, "output_partition_sizes", [])
+        fc, fcb = self._packed_operands(first)
+        sc, scb = self._packed_operands(second)
         return (first.codes.shape[0] == second.codes.shape[1] * second.codebooks.shape[3]
-                and ops.gemm_add_norm_supported(tokens, first.codes, first.codebooks, pf)
-                and ops.gemm_normed_supported(tokens, second.codes, second.codebooks, ps))
+                and ops.gemm_add_norm_supported(tokens, fc, fcb, pf)
+                and ops.gemm_normed_supported(tokens, sc, scb, ps))
 
     def norm_pair_preferred(self, first: torch.nn.Module, second: torch.nn.Module, tokens: int) -> bool:
         """norm_pair_supported, and the pair is not slower than the three separate steps: both GEMMs of the pair run
@@ -263,10 +289,10 @@ class PQLinearMethod(LinearMethodBase):
         if tokens <= 48:
             return True
         for layer in (first, second):
-            N, G, M = layer.codes.shape
-            cb = layer.codebooks
-            parts = list(getattr(cb, "output_partition_sizes", [])) or [N]
-            name = ops.gemm_kernel_name(tokens, N, G, M, cb.shape[1], cb.shape[3], layer.codes.element_size(),
+            pc, cb = self._packed_operands(layer)
+            N, G, M = pc.shape
+            parts = list(getattr(layer.codebooks, "output_partition_sizes", [])) or [N]
+            name = ops.gemm_kernel_name(tokens, N, G, M, cb.shape[1], cb.shape[3], pc.element_size(),
                                         cb.dtype, parts, packed=True)
             if name != "mfma_decode_packed":
                 return False
@@ -278,14 +304,16 @@ class PQLinearMethod(LinearMethodBase):
         50-80 with the fused add): `residual` becomes apply(x) + residual in place; returns (xw, ssq) for apply_normed
         of the linear behind the norm."""
         parts = getattr(layer.codebooks, "output_partition_sizes", [])
-        return ops.pq_gemm_packed_add_norm(x, layer.pq_packed_codes, layer.codes, layer.codebooks, layer.scales, parts,
+        pc, pcb = self._packed_operands(layer)
+        return ops.pq_gemm_packed_add_norm(x, layer.pq_packed_codes, pc, pcb, layer.scales, parts,
                                            bias, residual, norm_weight)
 
     def apply_normed(self, layer: torch.nn.Module, xw: torch.Tensor, ssq: torch.Tensor, eps: float,
                      bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         """apply(norm(...)) of the linear behind the norm, from what apply_add_norm returned."""
         parts = getattr(layer.codebooks, "output_partition_sizes", [])
-        return ops.pq_gemm_packed_normed(xw, ssq, eps, layer.pq_packed_codes, layer.codes, layer.codebooks, layer.scales,
+        pc, pcb = self._packed_operands(layer)
+        return ops.pq_gemm_packed_normed(xw, ssq, eps, layer.pq_packed_codes, pc, pcb, layer.scales,
                                          parts, bias)
 
     def apply_normed_silu_and_mul(self, layer: torch.nn.Module, xw: torch.Tensor, ssq: torch.Tensor, eps: float,
@@ -294,9 +322,10 @@ class PQLinearMethod(LinearMethodBase):
         the library fuses the activation into the GEMM behind the norm."""
         parts = list(getattr(layer.codebooks, "output_partition_sizes", []))
         tokens = xw.numel() // xw.shape[-1] if xw.shape[-1] else 0
+        pc, pcb = self._packed_operands(layer)
         if (len(parts) == 2 and parts[0] == parts[1] and layer.codes.shape[2] == 1
-                and ops.gemm_normed_silu_mul_supported(tokens, layer.codes, layer.codebooks)):
-            return ops.pq_gemm_packed_normed_silu_mul(xw, ssq, eps, layer.pq_packed_codes, layer.codes, layer.codebooks,
+                and ops.gemm_normed_silu_mul_supported(tokens, pc, pcb)):
+            return ops.pq_gemm_packed_normed_silu_mul(xw, ssq, eps, layer.pq_packed_codes, pc, pcb,
                                                       layer.scales, bias)
         y = self.apply_normed(layer, xw, ssq, eps, bias)
         out = torch.empty(y.shape[:-1] + (y.shape[-1] // 2,), dtype=y.dtype, device=y.device)
