@@ -89,12 +89,18 @@ static double stream_tall_model_us(const GemmArgs &a, int nf, int ksplit) {
     const int ks = (cg / 4) * a.d / 8;
     const double nchunks = (double)((a.G + cg - 1) / cg) / ksplit;
     const long blocks = (long)tiles_in(a.parts, nf * 16) * ((a.T + 15) / 16) * ksplit;
-    const double rounds = (double)((blocks + 255) / 256);
+    // (d = 2 with two-byte codes at a few tokens: two of its blocks share a CU -- measured on 8192 x 8192, a K split that
+    // doubles the grid to 512 blocks is 20 % shorter than the unsplit launch)
+    const bool pairs_share_cu = a.d == 2 && a.code_bytes == 2 && a.T <= 8;
+    const double rounds = (double)((blocks + (pairs_share_cu ? 511 : 255)) / (pairs_share_cu ? 512 : 256));
     const double per_wave = nchunks / 8.0 < 1.0 ? 1.0 : nchunks / 8.0;
     const int nsub = ks > 8 ? ks / 8 : 1;   // sub-loads per chunk at TF = 1
     const double scale = ks / 16.0;
     const double ld = a.packed && a.T >= 16 ? 0.85 : 1.0;   // activation loads with the lanes along the rows
-    const double chunks_us = scale * (1.0 * ld + 0.5 * nf) + (per_wave - 1.0) * (1.55 * ld * nsub + scale * 0.2 * nf);
+    // (a chunk of fewer than 8 k-steps has a shorter sub-load: measured on the d = 2 formats, where pricing it at the
+    // full 1.55 us made a K split look worth its hand-over at 16 tokens)
+    const double short_chunk = ks < 8 ? 0.5 + ks / 16.0 : 1.0;
+    const double chunks_us = scale * (1.0 * ld + 0.5 * nf) + (per_wave - 1.0) * (1.55 * ld * nsub * short_chunk + scale * 0.2 * nf);
     const double busy = nchunks / 8.0 < 1.0 ? nchunks / 8.0 : 1.0;   // waves of a block that have a chunk at all
     // (a second pass over the chip costs more than the first: measured 46.6 against a modelled 41.5 us, down_proj at 256 tokens)
     return rounds * (rounds > 1.0 ? 1.1 : 1.0) * (3.3 + 2.0 * busy + ksplit_us(a, ksplit) + chunks_us);
