@@ -253,3 +253,29 @@ def test_rows_helper_refuses_tensors_it_would_have_to_copy():
         ops._rows16(sliced, 64, "residual")
     with pytest.raises(ValueError):
         ops._rows16(torch.zeros(3, 32, dtype=torch.bfloat16), 64, "residual")
+
+
+@pytest.mark.parametrize("d", [2, 4])
+def test_fold_pairs_is_the_same_weight_on_cpu(d):
+    """ops.fold_pairs (host-side tensor operations, no kernel): the folded codes and 256-entry codebooks dequantise --
+    with the CPU oracle -- to the weight the original 16-entry format gives, bit for bit, partition by partition;
+    formats it cannot fold come back as None."""
+    import numpy as np
+    from oracle import pq_oracle as orc
+    from vllm_pq_amd import ops
+    g = torch.Generator().manual_seed(11 + d)
+    parts, G = [32, 16, 48], 24
+    N = sum(parts)
+    codes = torch.randint(-128, 128, (N, G, 1), generator=g, dtype=torch.int8)      # stored values reduce mod 16
+    cb = torch.randn(len(parts), 16, 1, d, generator=g).to(torch.bfloat16)
+    codes2, cb2 = ops.fold_pairs(codes, cb)
+    assert codes2.shape == (N, G // 2, 1) and codes2.dtype == torch.int8 and cb2.shape == (len(parts), 256, 1, 2 * d)
+    bits = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16)
+    ones = np.full(N, 0x3F80, dtype=np.uint16)                                      # scale 1.0 in bf16
+    want = orc.dequant(codes.numpy(), bits(cb).reshape(-1, 16, d), ones, parts, "bf16")
+    got = orc.dequant(codes2.numpy(), bits(cb2).reshape(-1, 256, 2 * d), ones, parts, "bf16")
+    assert np.array_equal(want, got)
+    assert ops.fold_pairs(codes[:, :23], cb) is None                                # odd number of groups
+    assert ops.fold_pairs(codes, torch.zeros(len(parts), 256, 1, d, dtype=torch.bfloat16)) is None
+    assert ops.fold_pairs(codes, torch.zeros(len(parts), 16, 1, 8, dtype=torch.bfloat16)) is None
+    assert ops.fold_pairs(codes.expand(N, G, 2), torch.zeros(2 * len(parts), 16, 1, d, dtype=torch.bfloat16)) is None
