@@ -757,3 +757,26 @@ def test_folded_pairs_through_the_method(ops):
         want = torch.empty_like(act)
         ops.silu_and_mul(want, y)
         assert (act.float() - want.float()).abs().max() <= 2.0 ** -6 * want.float().abs().max()
+
+
+@pytest.mark.parametrize("case", [c for c in G.cases("gemm") if c["K"] == 16 and c["d"] in (2, 4) and c["M"] == 1], ids=_id)
+def test_folded_pairs_against_the_reference_goldens(ops, case):
+    """The reference's own outputs for its 16-entry formats (golden vectors), reached through the folded tensors and
+    the packed entry point: the same bounds as the unfolded launch in test_gemm_golden."""
+    dt = case["dtype"]
+    codes, cb, sc = _golden_tensors(case)
+    folded = ops.fold_pairs(codes, cb)
+    if folded is None:
+        pytest.skip("odd number of groups")
+    codes2, cb2 = folded
+    packed2 = ops.pq_repack_codes(codes2, cb2, case["parts"])
+    assert packed2 is not None
+    x = tensor_of(G.get(case, "x"), dt, DEV)
+    b = G.get(case, "bias")
+    b = None if b is None else tensor_of(b, dt, DEV)
+    y = bits_of(ops.pq_gemm_packed(x, packed2, codes2, cb2, sc, case["parts"], b))
+    _, y32 = orc.gemm(G.get(case, "x"), G.get(case, "codes"), G.get(case, "codebooks").reshape(-1, case["K"], case["d"]),
+                      G.get(case, "scales").reshape(-1), case["parts"], G.get(case, "bias"), dt, order=2,
+                      acc_double=True, want_f32=True)
+    assert_close_to_exact(y, y32, dt, "vs exact")
+    assert_close_to_reference_order(y, G.get(case, "out"), dt, "vs reference output")
