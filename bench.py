@@ -217,7 +217,8 @@ class StepRunner:
                 torch.cuda.synchronize()
             if dist_on:
                 import torch.distributed as dist
-                ok = torch.tensor([1 if self.graph is not None else 0], dtype=torch.int32, device="cuda")
+                ok = torch.tensor([1 if self.graph is not None else 0], dtype=torch.int32,
+                                  device="cpu" if dist.get_backend() == "gloo" else "cuda")
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if int(ok.item()) == 0:
                     self.graph = None
@@ -246,7 +247,7 @@ def timed_steps(runner, steps, warmup, dist_on):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt

@@ -83,6 +83,13 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor, in_place: bool = Fals
     if _XGMI_AR is not None and _XGMI_AR.should_use(input_):
         return _XGMI_AR.all_reduce(input_, input_ if in_place else None)
     out = input_ if in_place and input_.is_contiguous() else input_.clone(memory_format=torch.contiguous_format)
+    if out.is_cuda and dist.get_backend(_TP_GROUP) == "gloo":
+        # a rehearsal of the multi-rank path without RCCL (several ranks on one GPU): gloo's own handling of device
+        # tensors was seen to hang between processes that share a device, so the sum goes through the host
+        host = out.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=_TP_GROUP)
+        out.copy_(host)
+        return out
     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=_TP_GROUP)
     return out
 
