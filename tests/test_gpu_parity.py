@@ -780,3 +780,52 @@ def test_folded_pairs_against_the_reference_goldens(ops, case):
                       acc_double=True, want_f32=True)
     assert_close_to_exact(y, y32, dt, "vs exact")
     assert_close_to_reference_order(y, G.get(case, "out"), dt, "vs reference output")
+
+
+# ---- a last partial round of the tiled kernel as a second launch of half-height tiles ------------------------
+@pytest.mark.parametrize("parts,split", [([2048, 1024, 512], 3), ([2048, 1024, 512], 4), ([2048, 1024, 512], 6),
+                                         ([1536, 1040], 2), ([1536, 1040], 4), ([4096], 5)])
+@pytest.mark.parametrize("T,bias", [(130, True), (512, False)])
+def test_tiled_kernel_split_launch(ops, monkeypatch, parts, split, T, bias):
+    """PQ_AMD_TILED_SPLIT = N: the first N 512-row tiles (in the tile map's order: every partition tiled separately,
+    ragged last tiles included) as one launch of 512 x 128 tiles, the remaining rows as a second launch of 256 x 128
+    tiles -- every output element written once, the same bits as the single launch (same sums in the same order)."""
+    p = Problem(900 + split, 256, 8, 1, parts, 1024, T, "bf16", bias=bias).to(DEV)
+    packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
+    monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "tiled")
+    monkeypatch.setenv("PQ_AMD_TILED_SPLIT", "0")
+    _lib.reload_knobs()
+    want = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    monkeypatch.setenv("PQ_AMD_TILED_SPLIT", str(split))
+    _lib.reload_knobs()
+    got = torch.full_like(want, float("nan"))
+    got = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
+    monkeypatch.delenv("PQ_AMD_TILED_SPLIT")
+    monkeypatch.delenv("PQ_AMD_FORCE_KERNEL")
+    _lib.reload_knobs()
+    assert torch.equal(got, want)
+    _, y32 = p.oracle_gemm(order=2)
+    assert_close_to_exact(bits_of(got), y32, "bf16")
+
+
+def test_tiled_kernel_split_chosen_by_the_model(ops):
+    """gate_up_proj of Llama-3-8B at 2048 tokens (896 tiles of 512 x 128: three and a half rounds of the chip): the
+    default dispatch splits the launch; the result is the bits of the unsplit launch."""
+    import os
+    torch.manual_seed(5)
+    parts, Kin, T = [14336, 14336], 4096, 2048
+    N, Gq = sum(parts), Kin // 8
+    codes = torch.randint(-128, 128, (N, Gq, 1), dtype=torch.int8, device=DEV)
+    cb = torch.randn(2, 256, 1, 8, device=DEV).to(torch.bfloat16)
+    scales = (torch.rand(N, 1, 1, 1, device=DEV) + 0.5).to(torch.bfloat16)
+    x = torch.randn(T, Kin, device=DEV).to(torch.bfloat16)
+    packed = ops.pq_repack_codes(codes, cb, parts)
+    y = ops.pq_gemm_packed(x, packed, codes, cb, scales, parts, None)
+    os.environ["PQ_AMD_TILED_SPLIT"] = "0"
+    _lib.reload_knobs()
+    try:
+        y0 = ops.pq_gemm_packed(x, packed, codes, cb, scales, parts, None)
+    finally:
+        del os.environ["PQ_AMD_TILED_SPLIT"]
+        _lib.reload_knobs()
+    assert torch.equal(y, y0)

@@ -111,7 +111,7 @@ Kernel choose(const pq::GemmArgs &a) {
 namespace pq {
 
 static Knobs read_knobs() {
-    Knobs k{-1, 0, 0, 0, -1, 0, 0, 0, 0, 0};
+    Knobs k{-1, 0, 0, 0, -1, 0, -1, 0, 0, 0, 0};
     const char *e = getenv("PQ_AMD_FORCE_KERNEL");
     if (e && *e) {
         if (!strcmp(e, "generic")) k.force_kernel = K_GENERIC;
@@ -128,6 +128,8 @@ static Knobs read_knobs() {
     if (e && *e) k.tiled_cfg = atoi(e);
     e = getenv("PQ_AMD_TILED_SLOTS");
     if (e && *e) k.tiled_slots = atoi(e);
+    e = getenv("PQ_AMD_TILED_SPLIT");
+    if (e && *e) k.tiled_split = atoi(e);
     e = getenv("PQ_AMD_DECODE_CFG");
     if (e && *e && sscanf(e, "%dx%d", &k.decode_waves, &k.decode_nf) != 2) k.decode_waves = k.decode_nf = 0;
     e = getenv("PQ_AMD_WIDE_CFG");
@@ -365,6 +367,11 @@ int pq_gemm_kernel_name(int32_t T, int32_t N, int32_t G, int32_t M, int32_t K, i
             double us = 0.0;
             const pq::StreamCfg c = pq::choose_stream_cfg(a, &us);
             snprintf(buf + n, buf_len - n, " %dx%d ks%d model %.1f us", c.nf, c.tf, c.ksplit, us);
+        } else if (k == K_TILED) {
+            int cfg = 0, split = 0;
+            pq::tiled_plan(a, &cfg, &split);
+            if (split > 0) snprintf(buf + n, buf_len - n, " cfg%d rows < %d, cfg1 from there", cfg, split);
+            else snprintf(buf + n, buf_len - n, " cfg%d", cfg);
         } else if (k == K_WIDE) {
             double us = 0.0;
             const pq::WideGeom g = pq::choose_wide_geom(a, &us);

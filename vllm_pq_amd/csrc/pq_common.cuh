@@ -72,16 +72,19 @@ struct TileMap {
     int row_end[PQ_MAX_PARTS];  // one past its last row
 };
 
-inline TileMap make_tile_map(const Parts &P, int rows_per_tile) {
+// Rows [lo, hi) of the layer only (a launch over part of the rows: every partition clipped to the range, its tiles
+// counted from the clipped start; a partition outside the range has no tiles and is never selected).
+inline TileMap make_tile_map_range(const Parts &P, int rows_per_tile, int lo, int hi) {
     TileMap m;
     int tile = 0, row = 0;
     for (int p = 0; p < PQ_MAX_PARTS; ++p) {
         if (p < P.num) {
+            const int a = row > lo ? row : lo, b = row + P.size[p] < hi ? row + P.size[p] : hi;
             m.tile0[p] = tile;
-            m.row0[p] = row;
+            m.row0[p] = a < b ? a : row;
+            m.row_end[p] = a < b ? b : row;
+            if (a < b) tile += (b - a + rows_per_tile - 1) / rows_per_tile;
             row += P.size[p];
-            m.row_end[p] = row;
-            tile += (P.size[p] + rows_per_tile - 1) / rows_per_tile;
         } else {
             m.tile0[p] = 0x7fffffff;
             m.row0[p] = row;
@@ -89,6 +92,20 @@ inline TileMap make_tile_map(const Parts &P, int rows_per_tile) {
         }
     }
     return m;
+}
+
+inline int tiles_in_range(const Parts &P, int rows_per_tile, int lo, int hi) {
+    int t = 0, row = 0;
+    for (int p = 0; p < P.num; ++p) {
+        const int a = row > lo ? row : lo, b = row + P.size[p] < hi ? row + P.size[p] : hi;
+        if (a < b) t += (b - a + rows_per_tile - 1) / rows_per_tile;
+        row += P.size[p];
+    }
+    return t;
+}
+
+inline TileMap make_tile_map(const Parts &P, int rows_per_tile) {
+    return make_tile_map_range(P, rows_per_tile, 0, 0x7fffffff);
 }
 
 __device__ inline TileLoc locate_tile(const TileMap &m, int tile, int rows_per_tile) {

@@ -973,17 +973,19 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tiled_kernel(
 }
 
 // ---- per-dtype launcher ---------------------------------------------------------------------------
+// (row_lo, row_hi: the launch covers these rows of the layer only -- the whole layer by default)
 template <typename AT, typename CodeT, int D, int M, int WAVES_T, int WN, int WT, int KT>
-static hipError_t tiled_launch_cfg(const GemmArgs &a, hipStream_t stream) {
+static hipError_t tiled_launch_cfg(const GemmArgs &a, hipStream_t stream, int row_lo = 0, int row_hi = 0x7fffffff) {
     constexpr int BN = (TL_WAVES / WAVES_T) * WN * 16;
     constexpr int BT = WAVES_T * WT * 16;
     // d = 2 with one-byte codes: 64 copies (a copy per lane; 256 bytes per entry, which the hand-pipelined stage's
     // gather addresses assume) -- 64 KiB at 256 entries
     const int R = (D == 2 && sizeof(CodeT) == 1) ? 64 : stream_replication<D>(a.K, a.M);
     const int nbits = __builtin_ctz((unsigned)a.K);
-    const int n_tiles = tiles_in(a.parts, BN);
+    const int n_tiles = tiles_in_range(a.parts, BN, row_lo, row_hi);
     const int t_tiles = (a.T + BT - 1) / BT;
     const int total = n_tiles * t_tiles;
+    if (total == 0) return hipSuccess;
     const int per_xcd = (total + 7) / 8;
     const size_t lds = (size_t)ST_MAX_LDS_CB + 3 * (size_t)KT * BT * TL_BK * 2;
     auto kern = gemm_tiled_kernel<AT, CodeT, D, M, WAVES_T, WN, WT, KT>;
@@ -1012,8 +1014,8 @@ static hipError_t tiled_launch_cfg(const GemmArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(nslots * 8), dim3(TL_THREADS), lds, stream, static_cast<const uint16_t *>(a.x), a.T,
                        a.x_stride, static_cast<const u32x4 *>(a.codes), static_cast<const uint16_t *>(a.codebooks),
                        static_cast<const uint16_t *>(a.scales), static_cast<const uint16_t *>(a.bias),
-                       make_tile_map(a.parts, BN), a.G, a.K, nbits, R, static_cast<uint16_t *>(a.y), a.y_stride, n_tiles,
-                       t_tiles);
+                       make_tile_map_range(a.parts, BN, row_lo, row_hi), a.G, a.K, nbits, R, static_cast<uint16_t *>(a.y),
+                       a.y_stride, n_tiles, t_tiles);
     return hipGetLastError();
 }
 
@@ -1046,7 +1048,10 @@ static TiledCfg tiled_cfg(const GemmArgs &a, int i) {
     return kTiledCfgs[i];
 }
 
-static int choose_tiled_cfg(const GemmArgs &a) {
+constexpr double kSpeed512x128 = 1.355, kSpeed256x128 = 1.24;   // d = 8, one codebook, one-byte codes
+
+static int choose_tiled_cfg(const GemmArgs &a, double *modelled = nullptr) {
+    if (modelled) *modelled = -1.0;
     if (knobs().tiled_cfg >= 0) {
         const int v = knobs().tiled_cfg;
         if (v >= 0 && v < kNumTiledCfgs && (a.G * a.d) % (64 * tiled_step_tiles(a, tiled_cfg(a, v).kt)) == 0) return v;
@@ -1055,7 +1060,8 @@ static int choose_tiled_cfg(const GemmArgs &a) {
     // block costs its tile area over the shape's measured throughput (PFLOP/s on a chip-filling problem:
     // bigger tiles reuse each gathered weight fragment and each activation fragment more often).  Padding
     // and half-filled last rounds are paid in full; ties go to the larger tile.
-    static const double speed_one[kNumTiledCfgs] = {1.33, 1.29, 1.085, 1.13, 0.856, 0.622, 1.355};
+    // (256 x 128 re-measured over several rounds of blocks on gate_up_proj: 49.4 us a round against 90 for 512 x 128)
+    static const double speed_one[kNumTiledCfgs] = {1.33, kSpeed256x128, 1.085, 1.13, 0.856, 0.622, kSpeed512x128};
     // two codebooks: every weight fragment is two gathers and eight rounded sums, so what counts is how many MFMAs a
     // fragment feeds -- 8 in the slots of the 256 x 256 and 128 x 128 shapes (256 x 256 and 128 x 256 tiles whose
     // waves take 8 token fragments), 4 or 2 elsewhere
@@ -1083,11 +1089,62 @@ static int choose_tiled_cfg(const GemmArgs &a) {
         const double cost = (double)((blocks + 255) / 256) * c.bn * c.bt / sp;
         if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = i; }
     }
+    if (modelled) *modelled = best_cost;
     return best;
+}
+
+// A last partial round.  The blocks run in rounds of one per CU, so 896 tiles of 512 x 128 (gate_up_proj of Llama-3-8B at
+// 2048 tokens) cost four rounds although they are three and a half.  Where the model says it pays, the layer is cut along
+// its rows: the first rows, as many 512-row tiles as fill whole rounds, run as one launch of 512 x 128 tiles, the rest as a
+// second launch of 256 x 128 tiles (half the height: the half round becomes a whole one).  Measured on that layer against
+// the best single launch, weights streaming from HBM (tools/ab_split.sh): 339 -> 330 us at 2048 tokens, 427 -> 409 at
+// 2560, 517 -> 496 at 3072; nothing to gain where the tiles fill whole rounds (4096 tokens: 1792 tiles = 7 rounds).
+// Returns the first row of the second launch, 0 for no split.
+static int choose_tiled_split(const GemmArgs &a) {
+    if (!(a.d == 8 && a.M == 1 && a.code_bytes == 1)) return 0;
+    const int forced = knobs().tiled_split;
+    if (forced == 0 || knobs().tiled_cfg >= 0) return 0;
+    if ((a.G * a.d) % (64 * 2)) return 0;                       // both shapes walk K in steps of two 64-k tiles
+    const int rtot = tiles_in(a.parts, 512);
+    const long t_tiles = (a.T + 127) / 128;
+    int r1;
+    if (forced > 0) {
+        r1 = forced;
+    } else {
+        const long full = rtot * t_tiles / 256;                 // whole rounds of 512 x 128 tiles
+        if (full < 1) return 0;
+        r1 = (int)(256 * full / t_tiles);
+    }
+    if (r1 < 1 || r1 >= rtot) return 0;
+    // the end row of the r1-th 512-row tile, in the map's order (every partition tiled separately)
+    int row = 0, left = r1, split = 0;
+    for (int p = 0; p < a.parts.num && left > 0; ++p) {
+        const int nt = (a.parts.size[p] + 511) / 512;
+        if (left >= nt) { left -= nt; row += a.parts.size[p]; split = row; }
+        else { split = row + left * 512; left = 0; }
+    }
+    if (split <= 0 || split >= a.N) return 0;
+    if (forced > 0) return split;
+    // rounds x tile area / measured throughput of the shape, plus what a second launch costs (12 us at 4096 inputs)
+    const double c6 = 512.0 * 128.0 / kSpeed512x128, c1 = 256.0 * 128.0 / kSpeed256x128, launch = 7000.0 * 4096.0 / (double)(a.G * a.d);
+    const long n1 = (long)r1 * t_tiles, n2 = (long)tiles_in_range(a.parts, 256, split, 0x7fffffff) * t_tiles;
+    double single = -1.0;
+    choose_tiled_cfg(a, &single);                               // the best single launch of any shape
+    if (single < 0.0) return 0;
+    const double two = (double)((n1 + 255) / 256) * c6 + (double)((n2 + 255) / 256) * c1 + launch;
+    return two < 0.98 * single ? split : 0;
 }
 
 template <typename AT, typename CodeT, int D, int M>
 static hipError_t tiled_launch_fmt(const GemmArgs &a, hipStream_t stream) {
+    if constexpr (D == 8 && M == 1 && sizeof(CodeT) == 1) {
+        const int split = choose_tiled_split(a);
+        if (split > 0) {
+            hipError_t e = tiled_launch_cfg<AT, CodeT, D, M, 2, 8, 4, 2>(a, stream, 0, split);          // 512 x 128
+            if (e != hipSuccess) return e;
+            return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 4, 2>(a, stream, split, 0x7fffffff);          // 256 x 128
+        }
+    }
     switch (choose_tiled_cfg(a)) {
     case 0:
         if constexpr (M == 2) return tiled_launch_cfg<AT, CodeT, D, M, 2, 4, 8, 1>(a, stream);   // 256 x 256, 8 token fragments a wave: every summed weight fragment feeds 8 MFMAs

@@ -119,6 +119,7 @@ hipError_t launch_repack(const void *codes, int N, int G, int M, int K, int d, i
 // Fused gather + MFMA, LDS-tiled activations (large T).
 bool gemm_tiled_supported(const GemmArgs &a);
 hipError_t launch_gemm_tiled(const GemmArgs &a, hipStream_t stream);
+void tiled_plan(const GemmArgs &a, int *cfg, int *split_row);   // tile shape index; first row of a second launch (0: none)
 
 // The element-wise neighbours of the linears (pq_elementwise.hip).  H = row length (for silu_and_mul: the
 // output's, the input row holds 2 H); residual != NULL selects the fused add.
