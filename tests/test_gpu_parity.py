@@ -785,12 +785,12 @@ def test_folded_pairs_against_the_reference_goldens(ops, case):
 # ---- a last partial round of the tiled kernel as a second launch of half-height tiles ------------------------
 @pytest.mark.parametrize("parts,split", [([2048, 1024, 512], 3), ([2048, 1024, 512], 4), ([2048, 1024, 512], 6),
                                          ([1536, 1040], 2), ([1536, 1040], 4), ([4096], 5)])
-@pytest.mark.parametrize("T,bias", [(130, True), (512, False)])
-def test_tiled_kernel_split_launch(ops, monkeypatch, parts, split, T, bias):
+@pytest.mark.parametrize("T,bias,dtype", [(130, True, "bf16"), (512, False, "bf16"), (300, True, "fp16")])
+def test_tiled_kernel_split_launch(ops, monkeypatch, parts, split, T, bias, dtype):
     """PQ_AMD_TILED_SPLIT = N: the first N 512-row tiles (in the tile map's order: every partition tiled separately,
     ragged last tiles included) as one launch of 512 x 128 tiles, the remaining rows as a second launch of 256 x 128
     tiles -- every output element written once, the same bits as the single launch (same sums in the same order)."""
-    p = Problem(900 + split, 256, 8, 1, parts, 1024, T, "bf16", bias=bias).to(DEV)
+    p = Problem(900 + split, 256, 8, 1, parts, 1024, T, dtype, bias=bias).to(DEV)
     packed = ops.pq_repack_codes(p.codes_dev, p.codebooks_dev, parts)
     monkeypatch.setenv("PQ_AMD_FORCE_KERNEL", "tiled")
     monkeypatch.setenv("PQ_AMD_TILED_SPLIT", "0")
@@ -798,14 +798,13 @@ def test_tiled_kernel_split_launch(ops, monkeypatch, parts, split, T, bias):
     want = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
     monkeypatch.setenv("PQ_AMD_TILED_SPLIT", str(split))
     _lib.reload_knobs()
-    got = torch.full_like(want, float("nan"))
     got = ops.pq_gemm_packed(p.x_dev, packed, p.codes_dev, p.codebooks_dev, p.scales_dev, parts, p.bias_dev)
     monkeypatch.delenv("PQ_AMD_TILED_SPLIT")
     monkeypatch.delenv("PQ_AMD_FORCE_KERNEL")
     _lib.reload_knobs()
     assert torch.equal(got, want)
     _, y32 = p.oracle_gemm(order=2)
-    assert_close_to_exact(bits_of(got), y32, "bf16")
+    assert_close_to_exact(bits_of(got), y32, dtype)
 
 
 def test_tiled_kernel_split_chosen_by_the_model(ops):
