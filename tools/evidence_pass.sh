@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-3 evidence pass on the GPU box: tiled stamps, mid-batch stamps, roofline sweep, exhaustive search, bench line.
-# Usage: bash tools/evidence_r03.sh <tag>
+# Short evidence pass on the GPU box (needs the lab binaries under tools/bin, which .gpurunignore keeps out of the push by default): tiled stamps, mid-batch stamps, roofline sweep, exhaustive search, bench line.
+# Usage: bash tools/evidence_pass.sh <tag>
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-pass}
 O=gpurun_out/evid_$TAG; mkdir -p $O
 timeout -k 10 120 ./tools/bin/tiled_lab 4096 s > $O/tiled_stamps.txt 2>&1 && echo tstamps ok &&
 timeout -k 10 200 ./tools/bin/wide_lab > $O/mid_stamps.txt 2>&1 && echo mid ok &&
