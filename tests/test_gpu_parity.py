@@ -828,3 +828,27 @@ def test_tiled_kernel_split_chosen_by_the_model(ops):
         del os.environ["PQ_AMD_TILED_SPLIT"]
         _lib.reload_knobs()
     assert torch.equal(y, y0)
+
+
+def test_folded_pairs_with_released_reference_codes(ops):
+    """release_reference_codes on a folded layer: the reference-layout codes give their storage back after the
+    load-time work, apply() keeps working from the packed folded codes."""
+    from vllm_pq_amd import PQConfig
+    from vllm_pq_amd.host.linear import RowParallelLinear
+    torch.manual_seed(3)
+    qc = PQConfig(4, 4, 1, 1, release_reference_codes=True)
+    layer = RowParallelLinear(2048, 512, bias=False, params_dtype=torch.bfloat16, quant_config=qc)
+    codes = torch.randint(-128, 128, layer.codes.shape, dtype=torch.int8)
+    layer.codes.data = codes.clone()
+    layer.codebooks.data = torch.randn(layer.codebooks.shape).to(torch.bfloat16)
+    layer.scales.data = (torch.rand(layer.scales.shape) + 0.5).to(torch.bfloat16)
+    layer.to(DEV)
+    w = ops.pq_dequant(layer.codes, layer.codebooks, [512])        # before the codes are released
+    layer.quant_method.process_weights_after_loading(layer)
+    assert layer.pq_folded is not None and layer.codes.untyped_storage().nbytes() <= 16
+    for T in (2, 40):
+        x = torch.randn(T, 2048, device=DEV).to(torch.bfloat16)
+        y, _ = layer(x)
+        ref = (x.float() @ w.float().t()) * layer.scales.view(1, -1).float()
+        tol = 0.51 * 2.0 ** -7 * ref.abs() + 1e-4 * ref.pow(2).mean().sqrt()
+        assert ((y.float() - ref).abs() <= tol).all()
